@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the SPH hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one iteration of the reference's simulate() loop body (SUMMER_SPH.f90:889-916):
+2 density passes + 2 force passes + 2 half-kicks + 1 drift + the dt reduction, on a seeded
+synthetic Keplerian disc (summersph_amd/ic.py).  Inputs are resident in HBM before the timed
+region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline     dominant kernel (forces): ALGORITHMIC HBM bytes per launch (SURVEY.md 8(d):
+               80 B read + 40 B written per particle) / its mean launch duration, measured with
+               HIP events on the library's own stream during the timed steps; peak 8 TB/s.
+  cpu_baseline the CPU oracle (oracle/sph_oracle.c, OpenMP over all host cores) timed on a
+               bounded sample of the same workload on this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per particle per pass
+BYTES = {"density": 40 + 8, "forces": 80 + 40, "kick": 80 + 40, "drift": 48 + 24}
+BYTES_PER_STEP = 2 * (BYTES["density"] + BYTES["forces"]) + 2 * BYTES["kick"] + BYTES["drift"]   # 648
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # vector fp64
+# fp64 operations per pair visit as written in the kernels (div/sqrt counted as 1 each)
+FLOPS_DENSITY_PAIR, FLOPS_FORCE_PAIR = 22, 75
+
+
+def cpu_baseline(n_total, nngb, seconds_target=15.0):
+    """CPU oracle on the host cores of this box, bounded sample (about seconds_target of CPU work)."""
+    from oracle import orc
+    from summersph_amd import ic
+    threads = orc.max_threads()
+    # calibrate on a small disc of the same surface density, then size the sample
+    rows = ic.keplerian_disc(20000, seed=1, nngb=nngb)
+    gas, sinks = ic.split_rows(rows)
+    o = orc.Oracle(gas, sinks, nthreads=threads)
+    t0 = time.perf_counter(); o.step(1e-2); t1 = time.perf_counter()
+    rate = 20000 / (t1 - t0)
+    n_s = int(min(n_total, max(20000, rate * seconds_target)))
+    rows = ic.keplerian_disc(n_s, seed=2, nngb=nngb)
+    gas, sinks = ic.split_rows(rows)
+    o = orc.Oracle(gas, sinks, nthreads=threads)
+    t0 = time.perf_counter(); o.step(1e-2); t1 = time.perf_counter()
+    return {"value": n_s / (t1 - t0), "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 full step (2 density + 2 force passes, kick/drift/dt) of a {n_s}-particle disc of the "
+                      f"same surface density, OpenMP x{threads}, {t1 - t0:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000, help="gas particles per GPU")
+    ap.add_argument("--nngb", type=float, default=85.0, help="midplane neighbour target of the IC (mean is ~0.7x)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--reuse-density", action="store_true", help="SPH_FLAG_REUSE_DENSITY (NOT the headline mode)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    from summersph_amd import capi, ic
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: seeded Keplerian disc, fixed h = 2.5 (the [F] path) ------------------------
+    rows = ic.keplerian_disc(args.n, seed=202 + rank, nngb=args.nngb)
+    gas, sinks = ic.split_rows(rows)
+    ctx = capi.Context(device=local_rank, flags=capi.FLAG_REUSE_DENSITY if args.reuse_density else 0)
+    dev = [torch.from_numpy(gas[k]).to(f"cuda:{local_rank}") for k in "x y z vx vy vz u m alpha".split()]
+    torch.cuda.synchronize()
+    ctx.upload_dev(args.n, [t.data_ptr() for t in dev])       # inputs resident in HBM
+    ctx.set_sinks(sinks)
+    del dev
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    dt, t = 1e-2, 0.0
+    dt, t = ctx.run(args.warmup, dt, t)
+    ctx.timing(True); ctx.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    dt, t = ctx.run(args.steps, dt, t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.timing(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        st = ctx.stats()
+        kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
+        f_ms, f_cnt = kt["forces"]
+        f_avg_s = f_ms / max(f_cnt, 1) * 1e-3
+        alg_bytes = BYTES["forces"] * args.n
+        achieved = alg_bytes / f_avg_s / 1e9
+        pairs_per_step = 2 * 2 * st.nlist_mean * args.n     # density + force visits, 2 evaluations
+        value = args.n * world * args.steps / elapsed
+        flops = (FLOPS_DENSITY_PAIR + FLOPS_FORCE_PAIR) * 2 * st.nlist_mean * args.n * args.steps / elapsed / 1e12
+        out = {
+            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"uniform Keplerian disc, {args.n} gas particles + 1 sink per GPU, fixed h=2.5 "
+                                   f"([F] path, BASELINE configs[1] shape at the metric's N=1e6), "
+                                   f"mean {st.nlist_mean:.1f} neighbours inside 2h, 2 density + 2 force passes per step",
+                       "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean,
+                       "max_neighbours": st.nlist_max, "grid": list(st.grid_dim),
+                       "reuse_density": bool(args.reuse_density),
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent shards (no halo exchange yet)"},
+            "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
+                         "note": "compulsory HBM traffic is tiny for this path; the pair loop is fp64-VALU / "
+                                 "gather bound, see valu_fp64"},
+            "valu_fp64": {"achieved_tflops_est": flops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": flops / FP64_PEAK_TFLOPS,
+                          "pair_visits_per_s": pairs_per_step * args.steps / elapsed},
+            "hbm_step": {"algorithmic_bytes_per_particle_step": BYTES_PER_STEP,
+                         "achieved_GBs": BYTES_PER_STEP * value / world / 1e9},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
+            "final_dt": dt, "device_bytes": st.device_bytes,
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.n, args.nngb)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/* summersph.h -- C ABI of the MI355X-native SPH core (libsummersph_hip.so).
+ *
+ * Drop-in boundary for the hot path of graves-andrew-02/SUMMERSPH: the calls `simulate`
+ * makes between tree allocation and the second `kick` (reference file
+ * SUMMER_SPH.f90, "[F]", lines 886-916).  The reference has no FFI; its de-facto interface
+ * is the set of module procedures listed beside each entry point below.  A Fortran
+ * maintainer binds these with `bind(C)` interfaces (summersph_amd/host/sph_hip_binding.f90,
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every entry point returns an int status (SPH_OK == 0); nothing aborts or prints.
+ *     sph_strerror() / sph_last_error() give text.
+ *   - caller-owned HOST arrays of double, contiguous, length n (struct-of-arrays); the
+ *     opaque context owns all device memory.  *_dev variants take DEVICE pointers instead
+ *     (inputs already resident in HBM).
+ *   - one context per GPU, one host thread per context (not re-entrant per context).
+ *   - particle order: whatever order the caller uploaded ("original order").  Internally
+ *     particles live cell-sorted; every download un-permutes.
+ *   - there is NO CPU fallback: without a HIP device sph_ctx_create fails with
+ *     SPH_ERR_NO_DEVICE.
+ */
+#ifndef SUMMERSPH_H
+#define SUMMERSPH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+typedef struct sph_ctx sph_ctx;
+
+enum sph_status {
+    SPH_OK = 0,
+    SPH_ERR_ARG = 1,          /* null pointer, negative size, bad field id ...            */
+    SPH_ERR_NO_DEVICE = 2,    /* no HIP device / device index out of range                */
+    SPH_ERR_HIP = 3,          /* a HIP runtime call failed (text in sph_last_error)       */
+    SPH_ERR_NOMEM = 4,        /* device or host allocation failed                         */
+    SPH_ERR_STATE = 5,        /* call order violated (e.g. forces before density)         */
+    SPH_ERR_GRID = 6,         /* cell grid would exceed 2^31 cells (non-finite positions?) */
+    SPH_ERR_NONFINITE = 7     /* NaN/Inf in particle positions at grid build               */
+};
+
+/* Runtime parameters.  Defaults (sph_params_default) are the reference's compile-time
+ * constants of SUMMER_SPH.f90, with REAL(4)-rounded literals reproduced bit for bit. */
+typedef struct sph_params {
+    double h;            /* smoothing length; [F]:11 smoothing = 2.5                      */
+    double gamma;        /* 1.4    ([F]:466)                                              */
+    double gamma_m1;     /* 0.4    ([F]:465 writes the literal 0.4_dp, not gamma-1)       */
+    int32_t nq;          /* 5000   ([F]:8) kernel-table intervals on q in [0,2]           */
+    int32_t flags;       /* SPH_FLAG_*                                                    */
+    double kernel_pi;    /* 3.14159265359 ([F]:125-126)                                   */
+    double visc_eps;     /* (double)0.01f  ([F]:373)                                      */
+    double alpha_floor;  /* 0.1    ([F]:317)                                              */
+    double alpha_decay;  /* (double)0.15f ([F]:317)                                       */
+    double G;            /* (double)39.47841760435743f ([F]:7)                            */
+    double dt_scale;     /* 0.25   ([F]:851)                                              */
+    double dt_max;       /* (double)0.1f    ([F]:855)                                     */
+    double dt_min;       /* (double)0.0001f ([F]:857)                                     */
+    double bounding_size;/* 1500   ([F]:11), used by sph_cull_bounds                      */
+} sph_params;
+
+/* flags */
+#define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
+                                    change since the last one (bitwise the same rho); OFF by
+                                    default: the reference recomputes it, [F]:896,908 */
+
+/* field ids for sph_download_field / sph_field_dev */
+enum sph_field {
+    SPH_F_X = 0, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA,
+    SPH_F_RHO, SPH_F_P, SPH_F_C, SPH_F_AX, SPH_F_AY, SPH_F_AZ, SPH_F_DU, SPH_F_DALPHA,
+    SPH_F_COUNT
+};
+
+/* kernels whose device time is recorded when timing is on */
+enum sph_kernel_id {
+    SPH_K_GRID = 0,    /* bbox + keys + sort + cell table + reorder                        */
+    SPH_K_NLIST,       /* neighbour-list build                                            */
+    SPH_K_DENSITY,     /* density + EOS                                                   */
+    SPH_K_FORCES,      /* sink gravity + SPH pair forces + alpha rate                     */
+    SPH_K_SINKACC,     /* acceleration of the sinks                                       */
+    SPH_K_KICK, SPH_K_DRIFT, SPH_K_DT,
+    SPH_K_COUNT
+};
+
+typedef struct sph_stats {
+    int64_t n;              /* gas particles                                              */
+    int64_t n_cells;        /* cells of the current grid                                  */
+    int32_t grid_dim[3];    /* cells along x, y, z                                        */
+    int32_t nlist_capacity; /* neighbour slots per particle currently allocated           */
+    int32_t nlist_max;      /* largest neighbour count found at the last build            */
+    double  nlist_mean;     /* mean neighbour count (pairs inside 2h, self excluded)      */
+    int64_t grid_builds, nlist_builds, density_passes, force_passes;
+    int64_t device_bytes;   /* HBM held by the context                                    */
+} sph_stats;
+
+/* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation
+ *      in simulate ([F]:894,901,905,928) ------------------------------------------------ */
+int sph_params_default(sph_params *p);
+int sph_ctx_create(const sph_params *p, int device, sph_ctx **out);
+int sph_ctx_destroy(sph_ctx *ctx);
+const char *sph_strerror(int status);
+const char *sph_last_error(const sph_ctx *ctx);
+int sph_abi_version(void);
+
+/* ---- state hand-over: replaces packing from `type(particle)` / `type(sink)` ([F]:14-37).
+ *      alpha may be NULL (-> 0, as the reader initialises it, [F]:681). ------------------ */
+int sph_upload(sph_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+               const double *vx, const double *vy, const double *vz,
+               const double *u, const double *m, const double *alpha);
+int sph_upload_dev(sph_ctx *ctx, int64_t n, const double *d_x, const double *d_y, const double *d_z,
+                   const double *d_vx, const double *d_vy, const double *d_vz,
+                   const double *d_u, const double *d_m, const double *d_alpha);
+int sph_set_sinks(sph_ctx *ctx, int32_t ns, const double *sx, const double *sy, const double *sz,
+                  const double *svx, const double *svy, const double *svz, const double *sm);
+/* any output pointer may be NULL */
+int sph_get_sinks(sph_ctx *ctx, int32_t ns, double *sx, double *sy, double *sz,
+                  double *svx, double *svy, double *svz, double *sm,
+                  double *sax, double *say, double *saz);
+int64_t sph_count(const sph_ctx *ctx);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+/* create_tree + get_density + get_pressure_and_sound_speed   ([F]:894-897, 398-468)      */
+int sph_density(sph_ctx *ctx);
+/* find_forces minus the Barnes-Hut gas self-gravity term: zero_rates, sink_gravforces,
+ * get_SPH   ([F]:818-829, 559-591, 295-395)                                              */
+int sph_forces(sph_ctx *ctx);
+/* kick ([F]:742-759) and drift ([F]:762-776), gas and sinks                              */
+int sph_kick(sph_ctx *ctx, double dt);
+int sph_drift(sph_ctx *ctx, double dt);
+/* get_next_timestep ([F]:831-860): in/out dt                                             */
+int sph_next_dt(sph_ctx *ctx, double *dt);
+/* one iteration of simulate's loop body, [F]:889-916: density, forces, kick, drift,
+ * density, forces, kick, t += dt, next dt.  Identical to the unfused call sequence.      */
+int sph_step(sph_ctx *ctx, double *dt, double *t);
+/* nsteps iterations without returning to the host in between (dt stays on the device)    */
+int sph_run(sph_ctx *ctx, int32_t nsteps, double *dt, double *t);
+
+/* ---- read-back, original particle order ---------------------------------------------- */
+int sph_download_field(sph_ctx *ctx, int field, double *host, int64_t n);
+int sph_download_field_dev(sph_ctx *ctx, int field, double *d_out, int64_t n);
+int sph_download_state(sph_ctx *ctx, int64_t n, double *x, double *y, double *z,
+                       double *vx, double *vy, double *vz, double *u, double *m, double *alpha);
+
+/* ---- diagnostics / measurement -------------------------------------------------------- */
+int sph_get_stats(sph_ctx *ctx, sph_stats *out);
+int sph_timing_enable(sph_ctx *ctx, int on);           /* HIP events around every kernel group */
+int sph_timing_reset(sph_ctx *ctx);
+int sph_timing_get(sph_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+int sph_synchronize(sph_ctx *ctx);
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*)      */
+void *sph_stream(sph_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMMERSPH_H */

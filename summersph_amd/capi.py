@@ -1,0 +1,230 @@
+"""ctypes binding of the C ABI (include/summersph.h) for the Python harness (tests, bench).
+
+This is plumbing only: every call goes straight to libsummersph_hip.so.  There is no fallback;
+if the library is missing or no GPU is present the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsummersph_hip.so")
+_D = C.POINTER(C.c_double)
+
+FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha"]
+KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt"]
+FLAG_REUSE_DENSITY = 1
+
+# every symbol include/summersph.h declares (tests check that the library exports them all)
+SYMBOLS = [
+    "sph_params_default", "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
+    "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
+    "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
+    "sph_download_field", "sph_download_field_dev", "sph_download_state",
+    "sph_get_stats", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("h", C.c_double), ("gamma", C.c_double), ("gamma_m1", C.c_double), ("nq", C.c_int32),
+                ("flags", C.c_int32), ("kernel_pi", C.c_double), ("visc_eps", C.c_double),
+                ("alpha_floor", C.c_double), ("alpha_decay", C.c_double), ("G", C.c_double),
+                ("dt_scale", C.c_double), ("dt_max", C.c_double), ("dt_min", C.c_double),
+                ("bounding_size", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_cells", C.c_int64), ("grid_dim", C.c_int32 * 3),
+                ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("nlist_mean", C.c_double),
+                ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
+                ("force_passes", C.c_int64), ("device_bytes", C.c_int64)]
+
+
+class SphError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"summersph status {status}: {text}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Loads libsummersph_hip.so (built by __graft_entry__.build() / make -C summersph_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME,
+    # libamdhip64.so.7, as /opt/rocm's).  Importing torch first makes the dynamic loader bind
+    # our library to that already-loaded runtime, so torch tensors (device memory, RCCL via
+    # torch.distributed) and this library share one set of devices and streams.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent: the system runtime in /opt/rocm/lib is used
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.sph_strerror.restype = C.c_char_p
+    lib.sph_last_error.restype = C.c_char_p
+    lib.sph_last_error.argtypes = [C.c_void_p]
+    lib.sph_count.restype = C.c_int64
+    lib.sph_count.argtypes = [C.c_void_p]
+    lib.sph_stream.restype = C.c_void_p
+    lib.sph_stream.argtypes = [C.c_void_p]
+    lib.sph_ctx_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+    lib.sph_ctx_destroy.argtypes = [C.c_void_p]
+    lib.sph_upload.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
+    lib.sph_upload_dev.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
+    lib.sph_set_sinks.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
+    lib.sph_get_sinks.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 10
+    for f in ("sph_density", "sph_forces", "sph_synchronize", "sph_timing_reset"):
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.sph_kick.argtypes = [C.c_void_p, C.c_double]
+    lib.sph_drift.argtypes = [C.c_void_p, C.c_double]
+    lib.sph_next_dt.argtypes = [C.c_void_p, _D]
+    lib.sph_step.argtypes = [C.c_void_p, _D, _D]
+    lib.sph_run.argtypes = [C.c_void_p, C.c_int32, _D, _D]
+    lib.sph_download_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.sph_download_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.sph_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def default_params() -> Params:
+    p = Params()
+    load().sph_params_default(C.byref(p))
+    return p
+
+
+def _hp(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+class Context:
+    """Thin object wrapper over an sph_ctx*.  Arrays are float64 numpy (host) unless a method says _dev."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, **overrides):
+        self.lib = load()
+        p = params if params is not None else default_params()
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        st = self.lib.sph_ctx_create(C.byref(p), int(device), C.byref(h))
+        if st != 0:
+            raise SphError(st, self.lib.sph_strerror(st).decode())
+        self._h = h
+
+    def _ck(self, st):
+        if st != 0:
+            raise SphError(st, self.lib.sph_strerror(st).decode() + " -- " + self.lib.sph_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.sph_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state -------------------------------------------------------------------------
+    @property
+    def n(self) -> int:
+        return int(self.lib.sph_count(self._h))
+
+    def upload(self, gas: dict):
+        arrs = [np.ascontiguousarray(gas[k], dtype=np.float64) for k in "x y z vx vy vz u m".split()]
+        al = gas.get("alpha")
+        al = None if al is None else np.ascontiguousarray(al, dtype=np.float64)
+        self._ck(self.lib.sph_upload(self._h, arrs[0].size, *[_hp(a) for a in arrs], _hp(al)))
+
+    def upload_dev(self, n: int, ptrs):
+        """ptrs: 9 device addresses (ints; alpha may be 0/None), e.g. torch tensors' data_ptr()"""
+        self._ck(self.lib.sph_upload_dev(self._h, int(n), *[C.c_void_p(int(p) if p else 0) for p in ptrs]))
+
+    def set_sinks(self, sinks: dict):
+        arrs = [np.ascontiguousarray(sinks[k], dtype=np.float64) for k in "x y z vx vy vz m".split()]
+        self._ck(self.lib.sph_set_sinks(self._h, arrs[0].size, *[_hp(a) for a in arrs]))
+        self.ns = int(arrs[0].size)
+
+    def get_sinks(self) -> dict:
+        ns = self.ns
+        out = {k: np.zeros(ns) for k in "x y z vx vy vz m ax ay az".split()}
+        self._ck(self.lib.sph_get_sinks(self._h, ns, *[_hp(out[k]) for k in "x y z vx vy vz m ax ay az".split()]))
+        return out
+
+    # ---- hot path ------------------------------------------------------------------------
+    def density(self):
+        self._ck(self.lib.sph_density(self._h))
+
+    def forces(self):
+        self._ck(self.lib.sph_forces(self._h))
+
+    def kick(self, dt: float):
+        self._ck(self.lib.sph_kick(self._h, float(dt)))
+
+    def drift(self, dt: float):
+        self._ck(self.lib.sph_drift(self._h, float(dt)))
+
+    def next_dt(self, dt: float) -> float:
+        d = C.c_double(dt)
+        self._ck(self.lib.sph_next_dt(self._h, C.byref(d)))
+        return d.value
+
+    def step(self, dt: float, t: float = 0.0):
+        d, tt = C.c_double(dt), C.c_double(t)
+        self._ck(self.lib.sph_step(self._h, C.byref(d), C.byref(tt)))
+        return d.value, tt.value
+
+    def run(self, nsteps: int, dt: float, t: float = 0.0):
+        d, tt = C.c_double(dt), C.c_double(t)
+        self._ck(self.lib.sph_run(self._h, int(nsteps), C.byref(d), C.byref(tt)))
+        return d.value, tt.value
+
+    # ---- read-back -----------------------------------------------------------------------
+    def field(self, name: str) -> np.ndarray:
+        out = np.zeros(self.n)
+        self._ck(self.lib.sph_download_field(self._h, FIELDS.index(name), _hp(out), out.size))
+        return out
+
+    def field_dev(self, name: str, dev_ptr: int, n: int):
+        self._ck(self.lib.sph_download_field_dev(self._h, FIELDS.index(name), C.c_void_p(int(dev_ptr)), int(n)))
+
+    def state(self) -> dict:
+        return {k: self.field(k) for k in FIELDS[:9]}
+
+    # ---- diagnostics ---------------------------------------------------------------------
+    def stats(self) -> Stats:
+        s = Stats()
+        self._ck(self.lib.sph_get_stats(self._h, C.byref(s)))
+        return s
+
+    def timing(self, on: bool):
+        self._ck(self.lib.sph_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._ck(self.lib.sph_timing_reset(self._h))
+
+    def timing_get(self, kernel: str):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._ck(self.lib.sph_timing_get(self._h, KERNELS.index(kernel), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def synchronize(self):
+        self._ck(self.lib.sph_synchronize(self._h))
+
+    def stream(self) -> int:
+        return int(self.lib.sph_stream(self._h) or 0)

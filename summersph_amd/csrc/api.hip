@@ -1,0 +1,486 @@
+// api.hip -- the C ABI of libsummersph_hip.so (declared in include/summersph.h).
+// Owns the context, device memory and the call-order state machine; all arithmetic lives in
+// grid.hip / pairs.hip / integrate.hip.  There is deliberately no CPU path here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "sph_internal.hpp"
+
+using namespace sph;
+
+namespace {
+
+#define API_HIP(expr)                                                       \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) {                                             \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+            return SPH_ERR_HIP;                                             \
+        }                                                                   \
+    } while (0)
+
+#define API_TRY(expr)                          \
+    do {                                       \
+        int _s = (expr);                       \
+        if (_s != SPH_OK) return _s;           \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_particle_arrays(sph_ctx *c) {
+    for (auto &p : c->f) ctx_free(c, p);
+    for (auto &p : c->f_alt) ctx_free(c, p);
+    ctx_free(c, c->orig); ctx_free(c, c->orig_alt); ctx_free(c, c->scratch);
+    ctx_free(c, c->drec); ctx_free(c, c->frec);
+    ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
+    ctx_free(c, c->sort_tmp);
+    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max);
+    c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
+}
+
+int ensure_capacity(sph_ctx *c, int64_t n) {
+    if (n <= c->cap) return SPH_OK;
+    free_particle_arrays(c);
+    const int64_t cap = n + n / 16 + 64;
+    for (auto &p : c->f) API_TRY(ctx_alloc(c, &p, (size_t)cap, "state"));
+    for (auto &p : c->f_alt) API_TRY(ctx_alloc(c, &p, (size_t)cap, "state (alt)"));
+    API_TRY(ctx_alloc(c, &c->orig, (size_t)cap, "ids"));
+    API_TRY(ctx_alloc(c, &c->orig_alt, (size_t)cap, "ids (alt)"));
+    API_TRY(ctx_alloc(c, &c->scratch, (size_t)cap, "scratch"));
+    API_TRY(ctx_alloc(c, &c->drec, (size_t)cap * 4, "density records"));
+    API_TRY(ctx_alloc(c, &c->frec, (size_t)cap * FREC, "force records"));
+    API_TRY(ctx_alloc(c, &c->keys, (size_t)cap, "keys"));
+    API_TRY(ctx_alloc(c, &c->keys_alt, (size_t)cap, "keys (alt)"));
+    API_TRY(ctx_alloc(c, &c->vals, (size_t)cap, "vals"));
+    API_TRY(ctx_alloc(c, &c->vals_alt, (size_t)cap, "vals (alt)"));
+    size_t tmp = 0;
+    API_HIP(grid_sort_tmp_bytes(cap, &tmp));
+    c->sort_tmp_bytes = tmp;
+    API_TRY(ctx_alloc_bytes(c, &c->sort_tmp, tmp ? tmp : 1, "sort scratch"));
+    c->nl_waves_cap = (cap + 63) / 64;
+    c->nl_cap = 96;   // grows on demand (nlist_build)
+    API_TRY(ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list"));
+    API_TRY(ctx_alloc(c, &c->ncount, (size_t)cap, "neighbour counts"));
+    API_TRY(ctx_alloc(c, &c->wave_max, (size_t)c->nl_waves_cap, "wave max"));
+    c->cap = cap;
+    return SPH_OK;
+}
+
+#pragma clang fp contract(off)
+void host_tables(int nq, std::vector<double> &w, std::vector<double> &dw) {
+    // SUMMER_SPH.f90:55-79 (cubic spline M4 sampled on q in [0,2]); dq = 2.0_dp/nq
+    w.assign((size_t)nq + 1, 0.0);
+    dw.assign((size_t)nq + 1, 0.0);
+    const double dq = 2.0 / nq;
+    for (int i = 0; i <= nq; i++) {
+        const double q = i * dq;
+        if (q >= 0.0 && q <= 1.0) {
+            w[i] = 1.0 - 1.5 * (q * q) + 0.75 * (q * q * q);
+            dw[i] = -3.0 * q + 2.25 * (q * q);
+        } else if (q > 1.0 && q <= 2.0) {
+            const double t = 2.0 - q;
+            w[i] = 0.25 * (t * t * t);
+            dw[i] = -0.75 * (t * t);
+        }
+    }
+}
+
+struct Timed {
+    sph_ctx *c; int id; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(sph_ctx *c_, int id_) : c(c_), id(id_) {
+        if (c->timing) {
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, c->stream);
+        }
+    }
+    ~Timed() {
+        if (e0) {
+            (void)hipEventRecord(e1, c->stream);
+            c->tslot[id].pending.emplace_back(e0, e1);
+        }
+    }
+};
+
+void resolve_timing(sph_ctx *c) {
+    for (auto &s : c->tslot) {
+        for (auto &pr : s.pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { s.total_ms += ms; s.launches++; }
+            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        }
+        s.pending.clear();
+    }
+}
+
+int do_density(sph_ctx *c) {
+    if (!c->grid_valid) {
+        { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
+        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
+        { Timed t(c, SPH_K_NLIST); API_TRY(nlist_build(c)); }
+        c->grid_valid = true;
+    }
+    const PairConst pc = make_pair_const(c);
+    Timed t(c, SPH_K_DENSITY);
+    if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
+        API_HIP(launch_eos_only(c, pc));
+    } else {
+        API_HIP(launch_density(c, pc));
+        c->density_passes++;
+    }
+    c->rho_valid = true; c->eos_valid = true;
+    return SPH_OK;
+}
+
+int do_forces(sph_ctx *c) {
+    if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces: call sph_density first"; return SPH_ERR_STATE; }
+    const PairConst pc = make_pair_const(c);
+    { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc)); }
+    c->force_passes++;
+    c->rates_valid = true;
+    return SPH_OK;
+}
+
+int do_kick(sph_ctx *c, double dt, bool dev) {
+    if (!c->rates_valid) { c->err = "sph_kick: rates are stale, call sph_forces first"; return SPH_ERR_STATE; }
+    Timed t(c, SPH_K_KICK);
+    API_HIP(launch_kick(c, dt, dev));
+    c->eos_valid = false;
+    return SPH_OK;
+}
+
+int do_drift(sph_ctx *c, double dt, bool dev) {
+    Timed t(c, SPH_K_DRIFT);
+    API_HIP(launch_drift(c, dt, dev));
+    c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
+    return SPH_OK;
+}
+
+int put_dt(sph_ctx *c, double dt, double t) {
+    c->h_pinned[16] = dt; c->h_pinned[17] = t; c->h_pinned[18] = 0.0;
+    API_HIP(hipMemcpyAsync(c->d_dt, c->h_pinned + 16, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return SPH_OK;
+}
+
+int get_dt(sph_ctx *c, double *dt, double *t) {
+    API_HIP(hipMemcpyAsync(c->h_pinned + 20, c->d_dt, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    API_HIP(hipStreamSynchronize(c->stream));
+    if (dt) *dt = c->h_pinned[20];
+    if (t) *t = c->h_pinned[21];
+    return SPH_OK;
+}
+
+int one_step_device_dt(sph_ctx *c) {
+    // SUMMER_SPH.f90:889-916
+    API_TRY(do_density(c));
+    API_TRY(do_forces(c));
+    API_TRY(do_kick(c, 0.0, true));
+    API_TRY(do_drift(c, 0.0, true));
+    API_TRY(do_density(c));
+    API_TRY(do_forces(c));
+    API_TRY(do_kick(c, 0.0, true));
+    Timed t(c, SPH_K_DT);
+    API_HIP(launch_next_dt(c, true));
+    return SPH_OK;
+}
+
+bool field_ready(const sph_ctx *c, int field) {
+    if (field <= SPH_F_ALPHA) return true;
+    if (field == SPH_F_RHO) return c->rho_valid;
+    if (field == SPH_F_P || field == SPH_F_C) return c->eos_valid || c->rates_valid;
+    return c->rates_valid;
+}
+
+}  // namespace
+
+namespace sph {
+
+int ctx_alloc_bytes(sph_ctx *c, void **p, size_t bytes, const char *what) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 8;
+    if (hipMalloc(p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        c->err = std::string("hipMalloc failed: ") + what;
+        return SPH_ERR_NOMEM;
+    }
+    c->allocs[*p] = bytes;
+    c->device_bytes += (int64_t)bytes;
+    return SPH_OK;
+}
+
+void ctx_free_ptr(sph_ctx *c, void *p) {
+    if (!p) return;
+    auto it = c->allocs.find(p);
+    if (it != c->allocs.end()) { c->device_bytes -= (int64_t)it->second; c->allocs.erase(it); }
+    (void)hipFree(p);
+}
+
+}  // namespace sph
+
+extern "C" {
+
+int sph_abi_version(void) { return SPH_ABI_VERSION; }
+
+const char *sph_strerror(int s) {
+    switch (s) {
+        case SPH_OK: return "ok";
+        case SPH_ERR_ARG: return "invalid argument";
+        case SPH_ERR_NO_DEVICE: return "no usable HIP device";
+        case SPH_ERR_HIP: return "HIP runtime error";
+        case SPH_ERR_NOMEM: return "out of memory";
+        case SPH_ERR_STATE: return "call order violated";
+        case SPH_ERR_GRID: return "cell grid too large";
+        case SPH_ERR_NONFINITE: return "non-finite particle position";
+        default: return "unknown status";
+    }
+}
+
+const char *sph_last_error(const sph_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int sph_params_default(sph_params *p) {
+    if (!p) return SPH_ERR_ARG;
+    std::memset(p, 0, sizeof(*p));
+    p->h = 2.5;                               // SUMMER_SPH.f90:11
+    p->gamma = 1.4; p->gamma_m1 = 0.4;        // :465-466
+    p->nq = 5000;                             // :8
+    p->flags = 0;
+    p->kernel_pi = 3.14159265359;             // :125-126
+    p->visc_eps = (double)0.01f;              // :373  (REAL(4) literal)
+    p->alpha_floor = 0.1;                     // :317
+    p->alpha_decay = (double)0.15f;           // :317  (REAL(4) literal)
+    p->G = (double)39.47841760435743f;        // :7    (REAL(4) literal)
+    p->dt_scale = 0.25;                       // :851
+    p->dt_max = (double)0.1f;                 // :855
+    p->dt_min = (double)0.0001f;              // :857
+    p->bounding_size = 1500.0;                // :11
+    return SPH_OK;
+}
+
+int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
+    if (!out) return SPH_ERR_ARG;
+    *out = nullptr;
+    sph_params dp;
+    if (!p) { sph_params_default(&dp); p = &dp; }
+    if (!(p->h > 0.0) || p->nq < 2 || p->nq > 19000 || !(p->gamma > 0.0)) return SPH_ERR_ARG;   // table must fit LDS
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return SPH_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return SPH_ERR_NO_DEVICE;
+    sph_ctx *c = new (std::nothrow) sph_ctx();
+    if (!c) return SPH_ERR_NOMEM;
+    c->p = *p;
+    c->device = device;
+    DeviceGuard g(device);
+    int st = SPH_OK;
+    auto fail = [&](int s) { sph_ctx_destroy(c); return s; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
+    std::memset(c->h_pinned, 0, 64 * sizeof(double));
+    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 8, "bbox")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->sink, (size_t)10 * MAX_SINKS, "sinks")) != SPH_OK) return fail(st);
+    c->sink_blocks = 512;
+    if ((st = ctx_alloc(c, &c->sink_part, (size_t)c->sink_blocks * MAX_SINKS * 3, "sink partials")) != SPH_OK) return fail(st);
+    c->dt_blocks = 1024;
+    if ((st = ctx_alloc(c, &c->dt_part, (size_t)c->dt_blocks, "dt partials")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->d_dt, 4, "dt")) != SPH_OK) return fail(st);
+    std::vector<double> w, dw;
+    host_tables(p->nq, w, dw);
+    if (hipMemcpy(c->w_tab, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->dw_tab, dw.data(), dw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->sink, 0, sizeof(double) * 10 * MAX_SINKS) != hipSuccess ||
+        hipMemset(c->d_dt, 0, sizeof(double) * 4) != hipSuccess)
+        return fail(SPH_ERR_HIP);
+    *out = c;
+    return SPH_OK;
+}
+
+int sph_ctx_destroy(sph_ctx *c) {
+    if (!c) return SPH_OK;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    resolve_timing(c);
+    free_particle_arrays(c);
+    ctx_free(c, c->cell_start); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
+    ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
+    ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPH_OK;
+}
+
+int64_t sph_count(const sph_ctx *c) { return c ? c->n : -1; }
+
+static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMemcpyKind kind) {
+    if (!c) return SPH_ERR_ARG;
+    if (n < 0 || n > 2000000000LL) { c->err = "sph_upload: bad n"; return SPH_ERR_ARG; }
+    for (int k = 0; k < 8; k++)
+        if (n > 0 && !src[k]) { c->err = "sph_upload: null array"; return SPH_ERR_ARG; }
+    DeviceGuard g(c->device);
+    API_TRY(ensure_capacity(c, n));
+    c->n = n;
+    for (int k = 0; k < 9; k++) {
+        if (n == 0) break;
+        if (src[k]) API_HIP(hipMemcpyAsync(c->f[k], src[k], (size_t)n * sizeof(double), kind, c->stream));
+        else API_HIP(hipMemsetAsync(c->f[k], 0, (size_t)n * sizeof(double), c->stream));   // alpha = 0, SUMMER_SPH.f90:681
+    }
+    API_HIP(launch_iota(c, c->orig, n));
+    API_HIP(hipStreamSynchronize(c->stream));
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = false;
+    return SPH_OK;
+}
+
+int sph_upload(sph_ctx *c, int64_t n, const double *x, const double *y, const double *z, const double *vx,
+               const double *vy, const double *vz, const double *u, const double *m, const double *alpha) {
+    const double *src[9] = {x, y, z, vx, vy, vz, u, m, alpha};
+    return upload_impl(c, n, src, hipMemcpyHostToDevice);
+}
+
+int sph_upload_dev(sph_ctx *c, int64_t n, const double *x, const double *y, const double *z, const double *vx,
+                   const double *vy, const double *vz, const double *u, const double *m, const double *alpha) {
+    const double *src[9] = {x, y, z, vx, vy, vz, u, m, alpha};
+    return upload_impl(c, n, src, hipMemcpyDeviceToDevice);
+}
+
+int sph_set_sinks(sph_ctx *c, int32_t ns, const double *sx, const double *sy, const double *sz, const double *svx,
+                  const double *svy, const double *svz, const double *sm) {
+    if (!c) return SPH_ERR_ARG;
+    if (ns < 0 || ns > MAX_SINKS) { c->err = "sph_set_sinks: 0 <= ns <= 64"; return SPH_ERR_ARG; }
+    const double *src[7] = {sx, sy, sz, svx, svy, svz, sm};
+    for (auto p : src) if (ns > 0 && !p) { c->err = "sph_set_sinks: null array"; return SPH_ERR_ARG; }
+    DeviceGuard g(c->device);
+    std::vector<double> buf((size_t)10 * MAX_SINKS, 0.0);
+    for (int k = 0; k < 7; k++) for (int s = 0; s < ns; s++) buf[(size_t)k * MAX_SINKS + s] = src[k][s];
+    API_HIP(hipStreamSynchronize(c->stream));
+    API_HIP(hipMemcpy(c->sink, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->ns = ns;
+    c->rates_valid = false;
+    return SPH_OK;
+}
+
+int sph_get_sinks(sph_ctx *c, int32_t ns, double *sx, double *sy, double *sz, double *svx, double *svy, double *svz,
+                  double *sm, double *sax, double *say, double *saz) {
+    if (!c || ns < 0 || ns > c->ns) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    std::vector<double> buf((size_t)10 * MAX_SINKS);
+    API_HIP(hipStreamSynchronize(c->stream));
+    API_HIP(hipMemcpy(buf.data(), c->sink, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double *dst[10] = {sx, sy, sz, svx, svy, svz, sm, sax, say, saz};
+    for (int k = 0; k < 10; k++) if (dst[k]) for (int s = 0; s < ns; s++) dst[k][s] = buf[(size_t)k * MAX_SINKS + s];
+    return SPH_OK;
+}
+
+int sph_density(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_density(c); }
+int sph_forces(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_forces(c); }
+int sph_kick(sph_ctx *c, double dt) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_kick(c, dt, false); }
+int sph_drift(sph_ctx *c, double dt) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_drift(c, dt, false); }
+
+int sph_next_dt(sph_ctx *c, double *dt) {
+    if (!c || !dt) return SPH_ERR_ARG;
+    if (!c->rates_valid) { c->err = "sph_next_dt: rates are stale"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    API_TRY(put_dt(c, *dt, 0.0));
+    { Timed t(c, SPH_K_DT); API_HIP(launch_next_dt(c, false)); }
+    return get_dt(c, dt, nullptr);
+}
+
+int sph_run(sph_ctx *c, int32_t nsteps, double *dt, double *t) {
+    if (!c || !dt || nsteps < 0) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_TRY(put_dt(c, *dt, t ? *t : 0.0));
+    for (int k = 0; k < nsteps; k++) API_TRY(one_step_device_dt(c));
+    return get_dt(c, dt, t);
+}
+
+int sph_step(sph_ctx *c, double *dt, double *t) { return sph_run(c, 1, dt, t); }
+
+int sph_download_field_dev(sph_ctx *c, int field, double *d_out, int64_t n) {
+    if (!c || field < 0 || field >= SPH_F_COUNT || n != c->n || (n > 0 && !d_out)) return SPH_ERR_ARG;
+    if (!field_ready(c, field)) { c->err = "sph_download_field: field is stale"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    API_HIP(launch_unpermute(c, c->f[field], d_out));
+    API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_download_field(sph_ctx *c, int field, double *host, int64_t n) {
+    if (!c || field < 0 || field >= SPH_F_COUNT || n != c->n || (n > 0 && !host)) return SPH_ERR_ARG;
+    if (!field_ready(c, field)) { c->err = "sph_download_field: field is stale"; return SPH_ERR_STATE; }
+    if (n == 0) return SPH_OK;
+    DeviceGuard g(c->device);
+    API_HIP(launch_unpermute(c, c->f[field], c->scratch));
+    API_HIP(hipMemcpyAsync(host, c->scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_download_state(sph_ctx *c, int64_t n, double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                       double *u, double *m, double *alpha) {
+    double *dst[9] = {x, y, z, vx, vy, vz, u, m, alpha};
+    for (int k = 0; k < 9; k++)
+        if (dst[k]) API_TRY(sph_download_field(c, k, dst[k], n));
+    return SPH_OK;
+}
+
+int sph_get_stats(sph_ctx *c, sph_stats *o) {
+    if (!c || !o) return SPH_ERR_ARG;
+    std::memset(o, 0, sizeof(*o));
+    o->n = c->n; o->n_cells = c->grid.ncells;
+    for (int a = 0; a < 3; a++) o->grid_dim[a] = c->grid.dim[a];
+    o->nlist_capacity = c->nl_cap; o->nlist_max = c->nl_max;
+    o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
+    o->density_passes = c->density_passes; o->force_passes = c->force_passes;
+    o->device_bytes = c->device_bytes;
+    if (c->n > 0 && c->grid_valid) {
+        DeviceGuard g(c->device);
+        std::vector<int32_t> cnt((size_t)c->n);
+        API_HIP(hipStreamSynchronize(c->stream));
+        API_HIP(hipMemcpy(cnt.data(), c->ncount, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        double s = 0.0;
+        for (int32_t v : cnt) s += v;
+        o->nlist_mean = s / (double)c->n;
+    }
+    return SPH_OK;
+}
+
+int sph_timing_enable(sph_ctx *c, int on) { if (!c) return SPH_ERR_ARG; c->timing = on != 0; return SPH_OK; }
+
+int sph_timing_reset(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    resolve_timing(c);
+    for (auto &s : c->tslot) { s.total_ms = 0.0; s.launches = 0; }
+    return SPH_OK;
+}
+
+int sph_timing_get(sph_ctx *c, int id, double *total_ms, int64_t *launches) {
+    if (!c || id < 0 || id >= SPH_K_COUNT) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    resolve_timing(c);
+    if (total_ms) *total_ms = c->tslot[id].total_ms;
+    if (launches) *launches = c->tslot[id].launches;
+    return SPH_OK;
+}
+
+int sph_synchronize(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+void *sph_stream(sph_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// grid.hip -- the neighbour index: uniform cell grid + radix-sorted particle order.
+//
+// Replaces the reference's pointer octree (create_tree / build_tree,
+// /root/reference/SUMMER_SPH.f90:795-816,149-246) for the fixed-h path.  Only the octree's
+// SEMANTICS are kept: for fixed h the tree walk visits exactly {j : |x_i - x_j| <= 2h}
+// (SURVEY.md 3.2), which a grid of edge 2h and a 27-cell stencil also covers.
+//
+// Pipeline per rebuild (all on ctx->stream):
+//   bbox_partial/bbox_final  -> bounding box (one small read-back: the host sizes the grid)
+//   cell_keys                -> 32-bit key per particle, axis with fewest cells fastest
+//   rocprim radix sort       -> stable (key, slot) sort on only as many bits as the grid needs
+//   cell_table               -> cell_start[c] = first sorted slot with key >= c
+//   reorder                  -> gathers the 9 state arrays + ids into sorted order and writes
+//                               the 32-byte density gather record {x,y,z,m}
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cmath>
+#include <utility>
+
+#include "sph_internal.hpp"
+
+namespace sph {
+
+namespace {
+
+constexpr int BB_BLOCK = 256;
+constexpr int BB_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// partial[b*6 + {0..2}] = min x,y,z ; {3..5} = max x,y,z over block b's grid-stride share
+__global__ __launch_bounds__(BB_BLOCK) void bbox_partial(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, int64_t n,
+                                                         double *__restrict__ partial, int32_t *__restrict__ flags) {
+    __shared__ double sm[6][BB_BLOCK / WAVE];
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * BB_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BB_BLOCK) {
+        double v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            bad |= !isfinite(v[a]);
+            lo[a] = fmin(lo[a], v[a]);
+            hi[a] = fmax(hi[a], v[a]);
+        }
+    }
+    if (bad) flags[0] = 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double mn = wave_min(lo[a]), mx = wave_max(hi[a]);
+        if (lane == 0) { sm[a][wv] = mn; sm[3 + a][wv] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int k = 1; k < BB_BLOCK / WAVE; k++)
+            r = threadIdx.x < 3 ? fmin(r, sm[threadIdx.x][k]) : fmax(r, sm[threadIdx.x][k]);
+        partial[(int64_t)blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
+__global__ void bbox_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < 6) {
+        double r = partial[t];
+        for (int b = 1; b < nblocks; b++) r = t < 3 ? fmin(r, partial[b * 6 + t]) : fmax(r, partial[b * 6 + t]);
+        out[t] = r;
+    }
+}
+
+__device__ __forceinline__ uint32_t cell_key(const GridDesc &g, double px, double py, double pz, int cc[3]) {
+    const double p[3] = {px, py, pz};
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int v = (int)((p[a] - g.org[a]) * g.inv_edge);
+        c[a] = min(max(v, 0), g.dim[a] - 1);
+    }
+    cc[0] = c[g.s[0]]; cc[1] = c[g.s[1]]; cc[2] = c[g.s[2]];
+    return ((uint32_t)cc[2] * (uint32_t)g.dim[g.s[1]] + (uint32_t)cc[1]) * (uint32_t)g.dim[g.s[0]] + (uint32_t)cc[0];
+}
+
+__global__ __launch_bounds__(256) void cell_keys(GridDesc g, const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, int64_t n, uint32_t *__restrict__ keys,
+                                                 uint32_t *__restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int cc[3];
+    keys[i] = cell_key(g, x[i], y[i], z[i], cc);
+    vals[i] = (uint32_t)i;
+}
+
+// cell_start[c] = lower_bound(sorted keys, c), c in [0, ncells]
+__global__ __launch_bounds__(256) void cell_table(const uint32_t *__restrict__ keys, int64_t n, int64_t ncells,
+                                                  int32_t *__restrict__ cell_start) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c > ncells) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cell_start[c] = (int32_t)lo;
+}
+
+struct ReorderArgs {
+    const double *src[9];
+    double *dst[9];
+};
+
+__global__ __launch_bounds__(256) void reorder(ReorderArgs a, const uint32_t *__restrict__ perm,
+                                               const int32_t *__restrict__ orig_in, int32_t *__restrict__ orig_out,
+                                               double *__restrict__ drec, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+    double v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = a.src[k][s];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.dst[k][i] = v[k];
+    orig_out[i] = orig_in[s];
+    double4 r = make_double4(v[SPH_F_X], v[SPH_F_Y], v[SPH_F_Z], v[SPH_F_M]);
+    reinterpret_cast<double4 *>(drec)[i] = r;
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int32_t *p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void unpermute(const double *__restrict__ src, const int32_t *__restrict__ orig,
+                                                 double *__restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[orig[i]] = src[i];
+}
+
+}  // namespace
+
+hipError_t grid_sort_tmp_bytes(int64_t n, size_t *bytes) {
+    size_t b = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (size_t)n, 0u, 32u, (hipStream_t) nullptr);
+    *bytes = b;
+    return e;
+}
+
+hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n) {
+    if (n <= 0) return hipSuccess;
+    iota_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(p, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_original) {
+    if (c->n <= 0) return hipSuccess;
+    unpermute<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(src_sorted, c->orig, dst_original, c->n);
+    return hipGetLastError();
+}
+
+// device-side cell key for the pair kernels lives in pairs.hip (same formula)
+
+#define GR_CHECK(expr)                                                      \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) {                                             \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+            return SPH_ERR_HIP;                                             \
+        }                                                                   \
+    } while (0)
+
+int grid_rebuild(sph_ctx *c) {
+    const int64_t n = c->n;
+    hipStream_t st = c->stream;
+    if (n == 0) { c->grid_valid = true; return SPH_OK; }
+
+    // ---- bounding box ---------------------------------------------------------------
+    int nb = (int)std::min<int64_t>((n + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
+    GR_CHECK(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 2, st));
+    bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], n, c->bbox_part, c->d_flags);
+    bbox_final<<<dim3(1), dim3(64), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
+    GR_CHECK(hipGetLastError());
+    GR_CHECK(hipMemcpyAsync(c->h_pinned, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    GR_CHECK(hipMemcpyAsync(c->h_pinned + 8, c->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GR_CHECK(hipStreamSynchronize(st));
+    if (*reinterpret_cast<int32_t *>(c->h_pinned + 8) != 0) {
+        c->err = "non-finite particle position at grid build";
+        return SPH_ERR_NONFINITE;
+    }
+    const double *bb = c->h_pinned;
+    GridDesc g{};
+    const double edge = 2.0 * c->p.h * (1.0 + 1e-6);
+    g.inv_edge = 1.0 / edge;
+    double ncell_d = 1.0;
+    for (int a = 0; a < 3; a++) {
+        g.org[a] = bb[a];
+        double ext = bb[3 + a] - bb[a];
+        double d = std::floor(ext * g.inv_edge) + 1.0;
+        if (!(d >= 1.0) || d > 2.0e9) { c->err = "cell grid dimension out of range"; return SPH_ERR_GRID; }
+        g.dim[a] = (int32_t)d;
+        ncell_d *= d;
+    }
+    if (ncell_d >= 2147483647.0) { c->err = "cell grid exceeds 2^31 cells"; return SPH_ERR_GRID; }
+    g.ncells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    // axis permutation: fewest cells fastest
+    int s[3] = {0, 1, 2};
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (g.dim[s[j]] < g.dim[s[i]]) std::swap(s[i], s[j]);
+    g.s[0] = s[0]; g.s[1] = s[1]; g.s[2] = s[2];
+    c->grid = g;
+
+    if (g.ncells + 1 > c->cell_cap) {
+        ctx_free(c, c->cell_start);
+        c->cell_cap = (g.ncells + 1) + (g.ncells + 1) / 4;
+        if (ctx_alloc(c, &c->cell_start, (size_t)c->cell_cap, "cell table") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
+    }
+
+    // ---- keys, sort, cell table ---------------------------------------------------------
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    cell_keys<<<dim3(gb), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], n, c->keys, c->vals);
+    GR_CHECK(hipGetLastError());
+    unsigned bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < g.ncells) bits++;
+    size_t tmp = c->sort_tmp_bytes;
+    GR_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->keys, c->keys_alt, c->vals, c->vals_alt, (size_t)n, 0u, bits, st));
+    cell_table<<<dim3((unsigned)((g.ncells + 1 + 255) / 256)), dim3(256), 0, st>>>(c->keys_alt, n, g.ncells, c->cell_start);
+    GR_CHECK(hipGetLastError());
+
+    // ---- reorder state into sorted slots --------------------------------------------------
+    ReorderArgs ra;
+    for (int k = 0; k < 9; k++) { ra.src[k] = c->f[k]; ra.dst[k] = c->f_alt[k]; }
+    reorder<<<dim3(gb), dim3(256), 0, st>>>(ra, c->vals_alt, c->orig, c->orig_alt, c->drec, n);
+    GR_CHECK(hipGetLastError());
+    for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
+    std::swap(c->orig, c->orig_alt);
+    c->grid_builds++;
+    return SPH_OK;
+}
+
+}  // namespace sph

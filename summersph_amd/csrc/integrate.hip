@@ -1,0 +1,138 @@
+// integrate.hip -- leapfrog kick / drift and the adaptive global time step.
+//
+// Replaces (citations: /root/reference/SUMMER_SPH.f90, "[F]")
+//   kick               [F]:742-759
+//   drift              [F]:762-776
+//   get_next_timestep  [F]:831-860
+// All three are pure HBM streaming kernels (80+40, 48+24 and 80 B per particle).  dt lives in
+// device memory (ctx->d_dt[0]) so that whole steps can be enqueued without a host round trip.
+#include <cmath>
+
+#include "sph_internal.hpp"
+
+namespace sph {
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int DT_BLOCK = 256;
+
+struct KickArgs {
+    double *vx, *vy, *vz, *u, *alpha;
+    const double *ax, *ay, *az, *du, *dalpha;
+};
+
+__global__ __launch_bounds__(EW_BLOCK) void kick_kernel(KickArgs a, int64_t n, double dt_val, const double *__restrict__ dt_ptr,
+                                                        double *__restrict__ sink, int ns) {
+    const double dt = dt_ptr ? dt_ptr[0] : dt_val;
+    const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i < n) {
+        a.vx[i] = a.vx[i] + 0.5 * a.ax[i] * dt;               // [F]:749-751
+        a.vy[i] = a.vy[i] + 0.5 * a.ay[i] * dt;
+        a.vz[i] = a.vz[i] + 0.5 * a.az[i] * dt;
+        a.u[i] = a.u[i] + 0.5 * a.du[i] * dt;                 // [F]:757
+        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;     // [F]:758
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ns) {                // [F]:753-755
+        const int s = threadIdx.x;
+        for (int k = 0; k < 3; k++)
+            sink[(3 + k) * MAX_SINKS + s] = sink[(3 + k) * MAX_SINKS + s] + 0.5 * sink[(7 + k) * MAX_SINKS + s] * dt;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void drift_kernel(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                                         const double *__restrict__ vx, const double *__restrict__ vy,
+                                                         const double *__restrict__ vz, int64_t n, double dt_val,
+                                                         const double *__restrict__ dt_ptr, double *__restrict__ sink, int ns) {
+    const double dt = dt_ptr ? dt_ptr[0] : dt_val;
+    const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i < n) {
+        x[i] = x[i] + vx[i] * dt;                             // [F]:769-771
+        y[i] = y[i] + vy[i] * dt;
+        z[i] = z[i] + vz[i] * dt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ns) {                // [F]:773-775
+        const int s = threadIdx.x;
+        for (int k = 0; k < 3; k++)
+            sink[k * MAX_SINKS + s] = sink[k * MAX_SINKS + s] + sink[(3 + k) * MAX_SINKS + s] * dt;
+    }
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// per-block minimum of the four candidates of [F]:845-850
+__global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict__ vx, const double *__restrict__ vy,
+                                                       const double *__restrict__ vz, const double *__restrict__ ax,
+                                                       const double *__restrict__ ay, const double *__restrict__ az,
+                                                       const double *__restrict__ u, const double *__restrict__ du,
+                                                       const double *__restrict__ cs, double h, int64_t n,
+                                                       double *__restrict__ part) {
+    __shared__ double sm[DT_BLOCK / WAVE];
+    double mn = INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
+        const double v2 = vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i];
+        const double a2 = ax[i] * ax[i] + ay[i] * ay[i] + az[i] * az[i];
+        const double c1 = sqrt(v2 / a2);                      // [F]:846
+        const double c2 = u[i] / fabs(du[i]);                 // [F]:847
+        const double c3 = h / sqrt(v2);                       // [F]:848
+        const double c4 = h / (cs[i] + 1.2 * cs[i]);          // [F]:849
+        mn = fmin(fmin(fmin(mn, c1), fmin(c2, c3)), c4);      // fmin skips NaN (0/0 candidates)
+    }
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < DT_BLOCK / WAVE; k++) mn = fmin(mn, sm[k]);
+        part[blockIdx.x] = mn;
+    }
+}
+
+// dtbuf: [0] dt, [1] t, [2] dt candidate.  [F]:851-859 (+ t = t + dt of [F]:914 when advance_t)
+__global__ void dt_final(const double *__restrict__ part, int nblocks, double dt_scale, double dt_max, double dt_min,
+                         int advance_t, double *__restrict__ dtbuf) {
+    double mn = INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 64) mn = fmin(mn, part[b]);
+    mn = wave_min(mn);
+    if (threadIdx.x == 0) {
+        const double cand = mn * dt_scale;                    // [F]:851
+        double dt = dtbuf[0];
+        if (advance_t) dtbuf[1] = dtbuf[1] + dt;              // [F]:914 (before the dt update)
+        if (cand > 2 * dt && 1.5 * dt < dt_max) dt = 1.5 * dt;            // [F]:855-856
+        else if (cand < 0.5 * dt && dt * 0.5 > dt_min) dt = 0.5 * dt;     // [F]:857-858
+        dtbuf[0] = dt;
+        dtbuf[2] = cand;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_kick(sph_ctx *c, double dt, bool dt_from_device) {
+    KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
+               c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]};
+    unsigned nb = (unsigned)std::max<int64_t>((c->n + EW_BLOCK - 1) / EW_BLOCK, 1);
+    kick_kernel<<<dim3(nb), dim3(EW_BLOCK), 0, c->stream>>>(a, c->n, dt, dt_from_device ? c->d_dt : nullptr, c->sink, c->ns);
+    return hipGetLastError();
+}
+
+hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device) {
+    unsigned nb = (unsigned)std::max<int64_t>((c->n + EW_BLOCK - 1) / EW_BLOCK, 1);
+    drift_kernel<<<dim3(nb), dim3(EW_BLOCK), 0, c->stream>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->f[SPH_F_VX],
+                                                              c->f[SPH_F_VY], c->f[SPH_F_VZ], c->n, dt,
+                                                              dt_from_device ? c->d_dt : nullptr, c->sink, c->ns);
+    return hipGetLastError();
+}
+
+hipError_t launch_next_dt(sph_ctx *c, bool advance_t) {
+    int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
+    if (nb < 1) nb = 1;
+    dt_partial<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_AX],
+                                                           c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_U], c->f[SPH_F_DU],
+                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part);
+    dt_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->p.dt_max, c->p.dt_min, advance_t ? 1 : 0, c->d_dt);
+    return hipGetLastError();
+}
+
+}  // namespace sph

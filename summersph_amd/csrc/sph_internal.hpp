@@ -1,0 +1,144 @@
+// sph_internal.hpp -- context layout and kernel-launcher declarations shared by the
+// translation units of libsummersph_hip.so.  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/summersph.h"
+
+namespace sph {
+
+constexpr int WAVE = 64;           // CDNA wavefront
+constexpr int FREC = 12;           // doubles per force gather record
+constexpr int MAX_SINKS = 64;      // sinks handled by the in-kernel loops
+
+// Uniform cell grid over the particles' bounding box.  Axes are permuted so that
+// axis s[0] (the one with the fewest cells) varies fastest in the cell key: for a disc
+// that is z, which keeps the three key-contiguous cells of a neighbour row short and the
+// nine rows of a 27-cell stencil close together in the sorted particle order.
+struct GridDesc {
+    double org[3];      // bbox minimum, natural x,y,z order
+    double inv_edge;    // 1 / cell edge, edge = 2h (1 + 1e-6)
+    int32_t dim[3];     // cells along x,y,z
+    int32_t s[3];       // axis permutation: s[0] fastest ... s[2] slowest
+    int64_t ncells;
+};
+
+// Constants every pair kernel needs; passed by value as a kernel argument (SGPRs).
+struct PairConst {
+    double h;            // smoothing length
+    double dq;           // 2/nq
+    double wnorm;        // kernel_pi * h^3        (W  is DIVIDED by this, [F]:125)
+    double dwnorm;       // kernel_pi * h^4        (dW is DIVIDED by this, [F]:126)
+    double visc_eps_h2;  // (0.01f * h) * h        ([F]:373)
+    double alpha_floor, alpha_decay, G, gamma, gamma_m1;
+    double rcut2;        // (2h)^2 (1 + 1e-12): filter only, the evaluation re-tests q <= 2
+    int32_t nq;
+    int32_t ns;          // sinks
+};
+
+struct TimingSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace sph
+
+struct sph_ctx {
+    sph_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int64_t n = 0;        // particles held
+    int64_t cap = 0;      // allocated particle slots
+
+    // cell-sorted struct-of-arrays state + derived + rates (SPH_F_* order)
+    double *f[SPH_F_COUNT] = {};
+    double *f_alt[9] = {};           // ping-pong targets for the 9 state fields on reorder
+    int32_t *orig = nullptr, *orig_alt = nullptr;   // sorted slot -> original index
+    double *scratch = nullptr;       // n doubles (un-permute on download)
+
+    // gather records (array-of-structs: one particle = one or few cache lines)
+    double *drec = nullptr;          // 4 doubles: x y z m
+    double *frec = nullptr;          // FREC doubles: x y z m vx vy vz rho P/rho^2 c alpha 0
+
+    // grid
+    sph::GridDesc grid{};
+    uint32_t *keys = nullptr, *keys_alt = nullptr, *vals = nullptr, *vals_alt = nullptr;
+    void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    int32_t *cell_start = nullptr; int64_t cell_cap = 0;
+    double *bbox_part = nullptr;     // per-block partial min/max
+    double *h_pinned = nullptr;      // pinned host scratch (bbox[6], flags, dt, ...)
+    int32_t *d_flags = nullptr;      // [0] nonfinite, [1] nlist max count
+
+    // neighbour list: slot k of particle i (wave w = i/64, lane = i%64) lives at
+    // nlist[(w*nl_cap + k)*64 + lane]  -> a wave reads 64 consecutive ints per k
+    int32_t *nlist = nullptr; int32_t nl_cap = 0; int64_t nl_waves_cap = 0;
+    int32_t *ncount = nullptr; int32_t *wave_max = nullptr;
+    int32_t nl_max = 0; double nl_mean = 0.0;
+
+    // kernel tables on the device
+    double *w_tab = nullptr, *dw_tab = nullptr;
+
+    // sinks on the device: 10 arrays of MAX_SINKS doubles: x y z vx vy vz m ax ay az
+    int32_t ns = 0;
+    double *sink = nullptr;
+    double *sink_part = nullptr;     // per-block partial sums for the sink accelerations
+    int32_t sink_blocks = 0;
+
+    // time step on the device: [0] dt, [1] t, [2] dt candidate
+    double *d_dt = nullptr;
+    double *dt_part = nullptr; int32_t dt_blocks = 0;
+
+    bool grid_valid = false;     // sorted order + cell table + neighbour list match positions
+    bool rho_valid = false;      // rho matches positions and masses
+    bool eos_valid = false;      // P, c, frec match rho, u, alpha, v
+    bool rates_valid = false;
+
+    // statistics and timing
+    int64_t grid_builds = 0, nlist_builds = 0, density_passes = 0, force_passes = 0;
+    int64_t device_bytes = 0;
+    std::unordered_map<void *, size_t> allocs;   // every device allocation of this context
+    bool timing = false;
+    sph::TimingSlot tslot[SPH_K_COUNT];
+};
+
+namespace sph {
+
+// device memory owned by the context (tracked so that sph_stats.device_bytes is exact)
+int ctx_alloc_bytes(sph_ctx *c, void **p, size_t bytes, const char *what);
+void ctx_free_ptr(sph_ctx *c, void *p);
+template <class T>
+inline int ctx_alloc(sph_ctx *c, T **p, size_t count, const char *what) {
+    return ctx_alloc_bytes(c, reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T), what);
+}
+template <class T>
+inline void ctx_free(sph_ctx *c, T *&p) {
+    ctx_free_ptr(c, p);
+    p = nullptr;
+}
+
+// all launchers enqueue on ctx->stream and return a hipError_t (no synchronisation unless noted)
+hipError_t grid_sort_tmp_bytes(int64_t n, size_t *bytes);
+// builds sorted order + cell table from the current positions.  Synchronises once (bbox read-back).
+int grid_rebuild(sph_ctx *c);
+// builds the neighbour list; synchronises once (overflow check), grows the list if needed
+int nlist_build(sph_ctx *c);
+hipError_t launch_density(sph_ctx *c, const PairConst &pc);
+hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc);
+hipError_t launch_forces(sph_ctx *c, const PairConst &pc);
+hipError_t launch_sink_accel(sph_ctx *c, const PairConst &pc);
+hipError_t launch_kick(sph_ctx *c, double dt, bool dt_from_device);
+hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device);
+hipError_t launch_next_dt(sph_ctx *c, bool advance_t);
+hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_original);
+hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n);
+PairConst make_pair_const(const sph_ctx *c);
+
+}  // namespace sph
