@@ -69,13 +69,16 @@ __global__ __launch_bounds__(BB_BLOCK) void bbox_partial(const double *__restric
     }
 }
 
-__global__ void bbox_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
-    const int t = threadIdx.x;
-    if (t < 6) {
-        double r = partial[t];
-        for (int b = 1; b < nblocks; b++) r = t < 3 ? fmin(r, partial[b * 6 + t]) : fmax(r, partial[b * 6 + t]);
-        out[t] = r;
+// 6 waves, one per bbox component; lanes stride over the per-block partials
+__global__ __launch_bounds__(384) void bbox_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+    const int comp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double r = comp < 3 ? INFINITY : -INFINITY;
+    for (int b = lane; b < nblocks; b += 64) {
+        const double v = partial[b * 6 + comp];
+        r = comp < 3 ? fmin(r, v) : fmax(r, v);
     }
+    r = comp < 3 ? wave_min(r) : wave_max(r);
+    if (lane == 0) out[comp] = r;
 }
 
 __device__ __forceinline__ uint32_t cell_key(const GridDesc &g, double px, double py, double pz, int cc[3]) {
@@ -187,7 +190,7 @@ int grid_rebuild(sph_ctx *c) {
     int nb = (int)std::min<int64_t>((n + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
     GR_CHECK(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 2, st));
     bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], n, c->bbox_part, c->d_flags);
-    bbox_final<<<dim3(1), dim3(64), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
+    bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
     GR_CHECK(hipGetLastError());
     GR_CHECK(hipMemcpyAsync(c->h_pinned, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     GR_CHECK(hipMemcpyAsync(c->h_pinned + 8, c->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));

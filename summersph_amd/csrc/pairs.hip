@@ -85,13 +85,21 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
                 if (c1 < 0 || c1 >= d1) continue;
                 const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
                 const int jb = cell_start[row + lo0], je = cell_start[row + hi0 + 1];
-                for (int j = jb; j < je; j++) {
-                    const double4 pj = drec[j];
-                    const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                    const double r2 = dx * dx + dy * dy + dz * dz;
-                    if (r2 <= rcut2 && j != (int)i) {
-                        if (cnt < cap) mine[(size_t)cnt * 64] = j;
-                        cnt++;
+                // 4 candidates per trip: the loads are independent, so four gathers are in flight
+                for (int j = jb; j < je; j += 4) {
+                    double r2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double4 pj = drec[min(j + u, je - 1)];
+                        const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                        r2[u] = dx * dx + dy * dy + dz * dz;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (j + u < je && r2[u] <= rcut2 && j + u != (int)i) {
+                            if (cnt < cap) mine[(size_t)cnt * 64] = j + u;
+                            cnt++;
+                        }
                     }
                 }
             }
@@ -105,66 +113,115 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
     }
 }
 
-// [F]:105-127 with the table in LDS.  S-normalisation is applied by the caller.
-__device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double dq, int nq) {
-    int k = (int)(qi / dq);
-    k = min(k, nq - 1);
-    const double a = (qi - k * dq) / dq;
+// ---- fp64 reciprocal / square root helpers ---------------------------------------------------
+// A full IEEE fp64 division costs ~20 VALU instructions on CDNA4 and the reference's pair term has
+// nine of them.  The kernels use the hardware seed (v_rcp_f64 / v_rsq_f64) plus Newton / Goldschmidt
+// steps instead: results are within ~1 ulp of the correctly rounded quotient, i.e. the same size as
+// the summation-order noise that is there anyway (parity tolerance 1e-13, tests/test_parity_gpu.py).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    return r;
+}
+
+// s = sqrt(x), rs = 1/sqrt(x) for x > 0 (x == 0 gives s = 0, rs = inf-free garbage the caller masks)
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &s, double &rs) {
+    const double xs = fmax(x, 1e-300);
+    double y = __builtin_amdgcn_rsq(xs);
+    double g = xs * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, xs);
+    g = fma(d, h, g);
+    s = x > 0.0 ? g : 0.0;
+    rs = h + h;
+}
+
+// lookup_kernel's interpolation, [F]:114-118, table in LDS; returns the un-normalised value.
+// k = min(int(q/dq), nq-1), a = (q - k dq)/dq  are evaluated as q*(1/dq): identical except within
+// an ulp of a table knot, where the (continuous) interpolant changes by O(1e-16).
+__device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double inv_dq, int nq) {
+    const double t = qi * inv_dq;
+    const int k = min((int)t, nq - 1);
+    const double a = t - (double)k;
     return (1.0 - a) * tab[k] + a * tab[k + 1];
 }
 
 // ------------------------------------------------------------------------------------------
 // density + EOS
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PAIR_BLOCK) void density_kernel(PairConst pc, const double4 *__restrict__ drec,
-                                                             const int32_t *__restrict__ nlist, int32_t cap,
-                                                             const int32_t *__restrict__ ncount,
-                                                             const int32_t *__restrict__ wave_max,
-                                                             const double *__restrict__ w_tab, int64_t n,
-                                                             const double *__restrict__ u, const double *__restrict__ alpha,
-                                                             const double *__restrict__ vx, const double *__restrict__ vy,
-                                                             const double *__restrict__ vz, double *__restrict__ rho,
-                                                             double *__restrict__ P, double *__restrict__ cs,
-                                                             double *__restrict__ frec) {
+// force gather record (FREC doubles): x y z m | vx vy vz rho/2 | P/rho^2  c/2  alpha/2  0
+// (halved values: 0.5*(a_i + a_j) == a_i/2 + a_j/2 exactly, which saves three multiplies per pair)
+__device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i, const double4 &pi, double vx, double vy,
+                                           double vz, double rho, double P, double c, double alpha) {
+    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
+    fr[0] = pi;
+    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
+    fr[2] = make_double4(P / (rho * rho), 0.5 * c, 0.5 * alpha, 0.0);       // [F]:381: P/(rho*rho)
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const double4 *__restrict__ drec,
+                                                        const int32_t *__restrict__ nlist, int32_t cap,
+                                                        const int32_t *__restrict__ ncount,
+                                                        const int32_t *__restrict__ wave_max,
+                                                        const double *__restrict__ w_tab, int64_t n,
+                                                        const double *__restrict__ u, const double *__restrict__ alpha,
+                                                        const double *__restrict__ vx, const double *__restrict__ vy,
+                                                        const double *__restrict__ vz, double *__restrict__ rho,
+                                                        double *__restrict__ P, double *__restrict__ cs,
+                                                        double *__restrict__ frec) {
     extern __shared__ double lds_w[];
-    for (int k = threadIdx.x; k <= pc.nq; k += PAIR_BLOCK) lds_w[k] = w_tab[k];
+    for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_w[k] = w_tab[k];
     __syncthreads();
 
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * PAIR_BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if ((i & ~(int64_t)63) >= n) return;   // whole wave out of range
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n;
-    const double4 pi = live ? drec[i] : make_double4(0, 0, 0, 0);
+    const int self = live ? (int)i : (int)(n - 1);
+    const double4 pi = drec[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
-    // self term: r = 0 -> W = w_table(0) = 1, [F]:443-455 visits the particle's own leaf too
-    double acc = live ? pi.w * (lds_w[0] / pc.wnorm) : 0.0;
+    // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
+    // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
+    // Lanes past their own count re-read their own record (a valid address) and are masked out.
+    int j1 = 0 < cnt ? mine[0] : self;
+    int j2 = 1 < cnt ? mine[64] : self;
+    double4 p1 = drec[j1];
+    double acc = 0.0;   // sum of m_j * w(q_ij), normalised once at the end
     for (int k = 0; k < kmax; k++) {
-        if (k < cnt) {
-            const int j = mine[(size_t)k * 64];
-            const double4 pj = drec[j];
-            const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;    // [F]:445
-            const double dr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);                   // [F]:446
-            const double qi = dr / pc.h;                                           // [F]:111
-            if (qi <= 2.0) {                                                       // [F]:113
-                const double Wj = table_lerp(lds_w, qi, pc.dq, pc.nq) / pc.wnorm;  // [F]:114-125
-                acc = acc + pj.w * Wj;                                             // [F]:454
-            }
-        }
+        const double4 pj = p1;
+        const bool act = k < cnt;
+        j1 = j2;
+        if (k + 2 < cnt) j2 = mine[(size_t)(k + 2) * 64];
+        if (k + 1 < cnt) p1 = drec[j1];          // idle lanes issue no gather
+        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
+        double dr, rs;
+        fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                   // [F]:446
+        const double qi = dr * inv_h;                                          // [F]:111
+        if (act && qi <= 2.0)                                                  // [F]:113
+            acc = fma(pj.w, table_lerp(lds_w, qi, inv_dq, pc.nq), acc);        // [F]:114-118,454
     }
     if (!live) return;
+    // self term (r = 0 -> w_table(0)): the tree walk visits the particle's own leaf too, [F]:443-455
+    acc = fma(pi.w, lds_w[0], acc);
+    const double rhoi = acc / pc.wnorm;                                        // [F]:125
     // EOS, [F]:465-466
     const double ui = u[i];
-    const double Pi = pc.gamma_m1 * ui * acc;
-    const double ci = sqrt(pc.gamma * Pi / acc);
-    rho[i] = acc; P[i] = Pi; cs[i] = ci;
-    double *fr = frec + (size_t)i * FREC;
-    reinterpret_cast<double4 *>(fr)[0] = pi;
-    reinterpret_cast<double4 *>(fr)[1] = make_double4(vx[i], vy[i], vz[i], acc);
-    reinterpret_cast<double4 *>(fr)[2] = make_double4(Pi / (acc * acc), ci, alpha[i], 0.0);   // [F]:381: P/(rho*rho)
+    const double Pi = pc.gamma_m1 * ui * rhoi;
+    const double ci = sqrt(pc.gamma * Pi / rhoi);
+    rho[i] = rhoi; P[i] = Pi; cs[i] = ci;
+    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi, ci, alpha[i]);
 }
 
 // P, c and the force records from an unchanged rho (SPH_FLAG_REUSE_DENSITY)
@@ -180,42 +237,85 @@ __global__ __launch_bounds__(256) void eos_only_kernel(PairConst pc, int64_t n, 
     const double Pi = pc.gamma_m1 * u[i] * r;
     const double ci = sqrt(pc.gamma * Pi / r);
     P[i] = Pi; cs[i] = ci;
-    double *fr = frec + (size_t)i * FREC;
-    reinterpret_cast<double4 *>(fr)[0] = drec[i];
-    reinterpret_cast<double4 *>(fr)[1] = make_double4(vx[i], vy[i], vz[i], r);
-    reinterpret_cast<double4 *>(fr)[2] = make_double4(Pi / (r * r), ci, alpha[i], 0.0);
+    write_frec(frec, i, drec[i], vx[i], vy[i], vz[i], r, Pi, ci, alpha[i]);
 }
 
 // ------------------------------------------------------------------------------------------
 // forces: sink gravity on the gas, SPH pressure + artificial viscosity, du/dt, dalpha/dt
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PAIR_BLOCK) void forces_kernel(PairConst pc, const double *__restrict__ frec,
-                                                            const int32_t *__restrict__ nlist, int32_t cap,
-                                                            const int32_t *__restrict__ ncount,
-                                                            const int32_t *__restrict__ wave_max,
-                                                            const double *__restrict__ dw_tab,
-                                                            const double *__restrict__ sink, int64_t n,
-                                                            double *__restrict__ ax, double *__restrict__ ay,
-                                                            double *__restrict__ az, double *__restrict__ du,
-                                                            double *__restrict__ dalpha) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const double *__restrict__ frec,
+                                                       const int32_t *__restrict__ nlist, int32_t cap,
+                                                       const int32_t *__restrict__ ncount,
+                                                       const int32_t *__restrict__ wave_max,
+                                                       const double *__restrict__ dw_tab,
+                                                       const double *__restrict__ sink, int64_t n,
+                                                       double *__restrict__ ax, double *__restrict__ ay,
+                                                       double *__restrict__ az, double *__restrict__ du,
+                                                       double *__restrict__ dalpha) {
     extern __shared__ double lds_dw[];
-    for (int k = threadIdx.x; k <= pc.nq; k += PAIR_BLOCK) lds_dw[k] = dw_tab[k];
+    for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_dw[k] = dw_tab[k];
     __syncthreads();
 
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * PAIR_BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if ((i & ~(int64_t)63) >= n) return;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n;
-    const int64_t ii = live ? i : 0;
-    const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)ii * FREC);
-    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho | P/rho^2 c alpha -
+    const int self = live ? (int)i : (int)(n - 1);
+    const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
+    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/rho^2 c/2 alpha/2 -
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
-    // zero_rates, then the gas side of sink_gravforces, [F]:567-576 (same order as find_forces)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, due = 0.0, dal = 0.0;
+    // SPH sums, un-normalised: every term is linear in dW, so 1/(pi h^4) ([F]:126) is applied once at the end
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
+
+    int j1 = 0 < cnt ? mine[0] : self;
+    int j2 = 1 < cnt ? mine[64] : self;
+    const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
+    double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
+    for (int k = 0; k < kmax; k++) {
+        const double4 Aj = A1, Bj = B1, Cj = C1;
+        const bool act = k < cnt;
+        j1 = j2;
+        if (k + 2 < cnt) j2 = mine[(size_t)(k + 2) * 64];
+        if (k + 1 < cnt) {                       // idle lanes issue no gather
+            fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
+            A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
+        }
+
+        const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;               // [F]:356
+        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+        double dr, rs;
+        fast_sqrt_rsqrt(r2, dr, rs);                                                  // [F]:357
+        const double qi = dr * inv_h;
+        // beyond 2h every term is exactly 0; r == 0 (coincident points): see DESIGN.md
+        if (act && qi <= 2.0 && r2 > 0.0) {
+            const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;           // [F]:358
+            const double vdotr = fmin(v0 * n0 + v1 * n1 + v2 * n2, 0.0);              // [F]:359-361
+            const double dWm = table_lerp(lds_dw, qi, inv_dq, pc.nq) * rs;            // [F]:366; rs: the 1/dr of [F]:363
+            const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                 // [F]:363,368
+            const double vdotgradW = g0 * v0 + g1 * v1 + g2 * v2;                     // [F]:370
+            const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);     // [F]:373
+            const double cbar = Cc.y + Cj.y;                                          // [F]:374 (halves stored)
+            const double abar = Cc.z + Cj.z;                                          // [F]:376
+            const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);   // [F]:378
+            const double Cf = Cc.x + Cj.x + visc;                                     // [F]:381-382
+            const double mj = Aj.w;
+            const double mC = mj * Cf;
+            s0 = fma(mC, g0, s0); s1 = fma(mC, g1, s1); s2 = fma(mC, g2, s2);         // [F]:383
+            const double mv = mj * vdotgradW;
+            sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                    // [F]:387
+            sdal += mv;                                                               // [F]:390
+        }
+    }
+    if (!live) return;
+
+    // zero_rates, then the gas side of sink_gravforces, [F]:567-576
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int s = 0; s < pc.ns; s++) {
         const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
         const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
@@ -223,39 +323,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void forces_kernel(PairConst pc, const 
         const double ms = sink[6 * MAX_SINKS + s];
         a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
     }
-
-    for (int k = 0; k < kmax; k++) {
-        if (k < cnt) {
-            const int j = mine[(size_t)k * 64];
-            const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j * FREC);
-            const double4 Aj = fj[0], Bj = fj[1], Cj = fj[2];
-            double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                 // [F]:356
-            const double dr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);                      // [F]:357
-            const double qi = dr / pc.h;
-            if (qi <= 2.0 && dr > 0.0) {    // beyond 2h every term is exactly 0; dr == 0: see DESIGN.md (coincident points)
-                const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;       // [F]:358
-                double vdotr = v0 * n0 + v1 * n1 + v2 * n2;                           // [F]:359
-                if (vdotr >= 0.0) vdotr = 0.0;                                        // [F]:361
-                n0 = n0 / dr; n1 = n1 / dr; n2 = n2 / dr;                             // [F]:363
-                const double dWm = table_lerp(lds_dw, qi, pc.dq, pc.nq) / pc.dwnorm;  // [F]:366,126
-                const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;             // [F]:368
-                const double vdotgradW = g0 * v0 + g1 * v1 + g2 * v2;                 // [F]:370
-                const double vis_nu = (pc.h * vdotr) / (dr * dr + pc.visc_eps_h2);    // [F]:373
-                const double cbar = 0.5 * (Cc.y + Cj.y);                              // [F]:374
-                const double abar = 0.5 * (Cc.z + Cj.z);                              // [F]:376
-                const double visc = (-abar * cbar * vis_nu + 2.0 * abar * vis_nu * vis_nu) / (0.5 * (B.w + Bj.w));  // [F]:378
-                const double Cf = Cc.x + Cj.x + visc;                                 // [F]:381-382
-                const double mj = Aj.w;
-                a0 = a0 - mj * (Cf * g0); a1 = a1 - mj * (Cf * g1); a2 = a2 - mj * (Cf * g2);   // [F]:383
-                due = due + mj * vdotgradW * (Cc.x + 0.5 * visc);                     // [F]:387
-                dal = dal + mj * vdotgradW;                                           // [F]:390
-            }
-        }
-    }
-    if (!live) return;
-    ax[i] = a0; ay[i] = a1; az[i] = a2; du[i] = due;
-    // [F]:317
-    dalpha[i] = fmax(dal / B.w, 0.0) + pc.alpha_decay * ((pc.alpha_floor - Cc.z) * Cc.y / pc.h);
+    const double inv_dwn = 1.0 / pc.dwnorm;
+    ax[i] = a0 - s0 * inv_dwn; ay[i] = a1 - s1 * inv_dwn; az[i] = a2 - s2 * inv_dwn;
+    du[i] = sdu * inv_dwn;
+    // [F]:317; rho_i = 2 B.w, c_i = 2 Cc.y, alpha_i = 2 Cc.z (exact)
+    dalpha[i] = fmax((sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / pc.h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -295,31 +367,30 @@ __global__ __launch_bounds__(SA_BLOCK) void sink_accel_partial(PairConst pc, con
     }
 }
 
-__global__ void sink_accel_final(PairConst pc, const double *__restrict__ part, int nblocks, double *__restrict__ sink) {
-    const int s = threadIdx.x;
-    if (s < pc.ns) {
-        double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-        for (int b = 0; b < nblocks; b++) {
-            const double *p = part + ((size_t)b * MAX_SINKS + s) * 3;
-            b0 += p[0]; b1 += p[1]; b2 += p[2];
-        }
-        sink[7 * MAX_SINKS + s] = b0; sink[8 * MAX_SINKS + s] = b1; sink[9 * MAX_SINKS + s] = b2;
-    }
-    __syncthreads();
-    // sink-sink pairs, [F]:578-590: serial, as in the reference (ns is tiny)
-    if (threadIdx.x == 0 && pc.ns >= 2) {
-        for (int i = 0; i < pc.ns; i++) {
-            for (int j = 0; j < i; j++) {
-                const double v0 = sink[0 * MAX_SINKS + j] - sink[0 * MAX_SINKS + i];
-                const double v1 = sink[1 * MAX_SINKS + j] - sink[1 * MAX_SINKS + i];
-                const double v2 = sink[2 * MAX_SINKS + j] - sink[2 * MAX_SINKS + i];
-                const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-                const double d3 = dr * dr * dr;
-                const double w0 = pc.G * v0 / d3, w1 = pc.G * v1 / d3, w2 = pc.G * v2 / d3;
-                const double mi = sink[6 * MAX_SINKS + i], mj = sink[6 * MAX_SINKS + j];
-                sink[7 * MAX_SINKS + i] += mj * w0; sink[8 * MAX_SINKS + i] += mj * w1; sink[9 * MAX_SINKS + i] += mj * w2;
-                sink[7 * MAX_SINKS + j] -= mi * w0; sink[8 * MAX_SINKS + j] -= mi * w1; sink[9 * MAX_SINKS + j] -= mi * w2;
-            }
+// one block per sink, one wave per component: lanes stride over the per-block partials, then a
+// fixed-order wave reduction (bitwise reproducible)
+__global__ __launch_bounds__(192) void sink_accel_final(const double *__restrict__ part, int nblocks, double *__restrict__ sink) {
+    const int s = blockIdx.x, comp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double b = 0.0;
+    for (int k = lane; k < nblocks; k += 64) b += part[((size_t)k * MAX_SINKS + s) * 3 + comp];
+    b = wave_sum(b);
+    if (lane == 0) sink[(7 + comp) * MAX_SINKS + s] = b;
+}
+
+// sink-sink pairs, [F]:578-590: serial, as in the reference (ns is tiny)
+__global__ void sink_sink_kernel(PairConst pc, double *__restrict__ sink) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < pc.ns; i++) {
+        for (int j = 0; j < i; j++) {
+            const double v0 = sink[0 * MAX_SINKS + j] - sink[0 * MAX_SINKS + i];
+            const double v1 = sink[1 * MAX_SINKS + j] - sink[1 * MAX_SINKS + i];
+            const double v2 = sink[2 * MAX_SINKS + j] - sink[2 * MAX_SINKS + i];
+            const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+            const double d3 = dr * dr * dr;
+            const double w0 = pc.G * v0 / d3, w1 = pc.G * v1 / d3, w2 = pc.G * v2 / d3;
+            const double mi = sink[6 * MAX_SINKS + i], mj = sink[6 * MAX_SINKS + j];
+            sink[7 * MAX_SINKS + i] += mj * w0; sink[8 * MAX_SINKS + i] += mj * w1; sink[9 * MAX_SINKS + i] += mj * w2;
+            sink[7 * MAX_SINKS + j] -= mi * w0; sink[8 * MAX_SINKS + j] -= mi * w1; sink[9 * MAX_SINKS + j] -= mi * w2;
         }
     }
 }
@@ -381,7 +452,7 @@ int nlist_build(sph_ctx *c) {
 hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
-    density_kernel<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
+    density_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->n,
         c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P],
         c->f[SPH_F_C], c->frec);
@@ -399,7 +470,7 @@ hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc) {
 hipError_t launch_forces(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
-    forces_kernel<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
+    forces_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]);
     return hipGetLastError();
@@ -411,7 +482,8 @@ hipError_t launch_sink_accel(sph_ctx *c, const PairConst &pc) {
     if (nb < 1) nb = 1;
     sink_accel_partial<<<dim3(nb), dim3(SA_BLOCK), 0, c->stream>>>(pc, reinterpret_cast<const double4 *>(c->drec), c->n,
                                                                     c->sink, c->sink_part);
-    sink_accel_final<<<dim3(1), dim3(MAX_SINKS), 0, c->stream>>>(pc, c->sink_part, nb, c->sink);
+    sink_accel_final<<<dim3(pc.ns), dim3(192), 0, c->stream>>>(c->sink_part, nb, c->sink);
+    if (pc.ns >= 2) sink_sink_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(pc, c->sink);
     return hipGetLastError();
 }
 
