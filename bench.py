@@ -40,7 +40,7 @@ def cpu_baseline(n_total, nngb, seconds_target=15.0):
     """CPU oracle on the host cores of this box, bounded sample (about seconds_target of CPU work)."""
     from oracle import orc
     from summersph_amd import ic
-    threads = orc.max_threads()
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
     # calibrate on a small disc of the same surface density, then size the sample
     rows = ic.keplerian_disc(20000, seed=1, nngb=nngb)
     gas, sinks = ic.split_rows(rows)
@@ -82,14 +82,30 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload: seeded Keplerian disc, fixed h = 2.5 (the [F] path) ------------------------
-    rows = ic.keplerian_disc(args.n, seed=202 + rank, nngb=args.nngb)
+    # weak scaling: the disc holds n x world particles (same surface density, larger radius) and
+    # every rank owns one equal-count slab of it
+    rows = ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb)
     gas, sinks = ic.split_rows(rows)
-    ctx = capi.Context(device=local_rank, flags=capi.FLAG_REUSE_DENSITY if args.reuse_density else 0)
-    dev = [torch.from_numpy(gas[k]).to(f"cuda:{local_rank}") for k in "x y z vx vy vz u m alpha".split()]
-    torch.cuda.synchronize()
-    ctx.upload_dev(args.n, [t.data_ptr() for t in dev])       # inputs resident in HBM
-    ctx.set_sinks(sinks)
-    del dev
+    flags = capi.FLAG_REUSE_DENSITY if args.reuse_density else 0
+    if world == 1:
+        ctx = capi.Context(device=local_rank, flags=flags)
+        dev = [torch.from_numpy(gas[k]).to(f"cuda:{local_rank}") for k in "x y z vx vy vz u m alpha".split()]
+        torch.cuda.synchronize()
+        ctx.upload_dev(args.n, [t.data_ptr() for t in dev])       # inputs resident in HBM
+        ctx.set_sinks(sinks)
+        del dev
+        sim = None
+    else:
+        from summersph_amd.dist import DistSim, HipBackend, slab_bounds
+        bounds = slab_bounds(gas["x"], world)
+        owner = np.searchsorted(bounds, gas["x"], side="right")
+        sel = owner == rank
+        mine = {k: v[sel] for k, v in gas.items()}
+        mine["gid"] = np.nonzero(sel)[0]
+        be = HipBackend(local_rank, flags=flags)
+        sim = DistSim(be, mine, sinks, bounds, group=None)          # device tensors over RCCL
+        ctx = be.ctx
+    del rows, gas
 
     def barrier():
         ctx.synchronize()
@@ -97,19 +113,32 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def run(k, dt, t):
+        if sim is None:
+            return ctx.run(k, dt, t)
+        for _ in range(k):
+            dt = sim.step(dt)
+        return dt, sim.t
+
     dt, t = 1e-2, 0.0
-    dt, t = ctx.run(args.warmup, dt, t)
+    dt, t = run(args.warmup, dt, t)
     ctx.timing(True); ctx.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    dt, t = ctx.run(args.steps, dt, t)
+    dt, t = run(args.steps, dt, t)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.timing(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    n_loc = torch.tensor([float(sim.n_owned if sim is not None else args.n), float(sim.stats["ghosts"] if sim is not None else 0)],
+                         dtype=torch.float64, device=f"cuda:{local_rank}")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        n_max = n_loc.clone()
+        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+    else:
+        n_max = n_loc
     elapsed = float(el.item())
 
     if rank == 0:
@@ -117,6 +146,7 @@ def main():
         kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
         f_ms, f_cnt = kt["forces"]
         f_avg_s = f_ms / max(f_cnt, 1) * 1e-3
+        n_slots = st.n                                      # owned + ghosts held by rank 0's context
         alg_bytes = BYTES["forces"] * args.n
         achieved = alg_bytes / f_avg_s / 1e9
         pairs_per_step = 2 * 2 * st.nlist_mean * args.n     # density + force visits, 2 evaluations
@@ -133,7 +163,10 @@ def main():
                        "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean,
                        "max_neighbours": st.nlist_max, "grid": list(st.grid_dim),
                        "reuse_density": bool(args.reuse_density),
-                       "parallelism": "1 GPU" if world == 1 else f"{world} independent shards (no halo exchange yet)"},
+                       "parallelism": "1 GPU" if world == 1 else
+                                      f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed nccl)",
+                       "max_owned_per_gpu": int(n_max[0].item()), "max_ghosts_per_gpu": int(n_max[1].item()),
+                       "rank0_slots": int(n_slots)},
             "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,

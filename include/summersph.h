@@ -145,8 +145,31 @@ int sph_download_field_dev(sph_ctx *ctx, int field, double *d_out, int64_t n);
 int sph_download_state(sph_ctx *ctx, int64_t n, double *x, double *y, double *z,
                        double *vx, double *vy, double *vz, double *u, double *m, double *alpha);
 
+/* ---- multi-GPU building blocks (one context per GPU; orchestration: summersph_amd/dist.py) --
+ * A context may hold GHOST particles: copies of other GPUs' particles that lie within 2h of
+ * this GPU's domain.  Upload owned particles first and ghosts after them, then declare how
+ * many are owned: original ids [n_owned, n) are ghosts.  Ghosts act as neighbours in the
+ * density and force sums but are never targets (no rho, rates, dt candidate or sink pull is
+ * computed for them); their rho comes from their owner through sph_scatter_field_dev.      */
+int sph_set_owned(sph_ctx *ctx, int64_t n_owned);
+int sph_set_rank(sph_ctx *ctx, int32_t rank, int32_t nranks);
+/* field[slot of original id first+k] = d_vals[k], k in [0,count): refreshes ghost rho after the
+ * owners' density pass, or ghost v, u, alpha after a kick.                                 */
+int sph_scatter_field_dev(sph_ctx *ctx, int field, int64_t first, int64_t count, const double *d_vals);
+/* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */
+int sph_refresh_eos(sph_ctx *ctx);
+/* the local part of get_next_timestep ([F]:845-851): min over OWNED particles * dt_scale;
+ * the caller min-reduces over ranks and applies [F]:855-858                                */
+int sph_dt_candidate(sph_ctx *ctx, double *candidate);
+/* overwrite the sink accelerations (after summing the per-GPU partial sums over ranks)     */
+int sph_set_sink_accel(sph_ctx *ctx, int32_t ns, const double *sax, const double *say, const double *saz);
+
 /* ---- diagnostics / measurement -------------------------------------------------------- */
 int sph_get_stats(sph_ctx *ctx, sph_stats *out);
+/* bounding box of the particle positions at the last grid build (= the current positions
+ * after sph_density / sph_step): lo[3], hi[3].  Serves check_bounds ([F]:471-482) without a
+ * download.                                                                              */
+int sph_get_bbox(sph_ctx *ctx, double *lo, double *hi);
 int sph_timing_enable(sph_ctx *ctx, int on);           /* HIP events around every kernel group */
 int sph_timing_reset(sph_ctx *ctx);
 int sph_timing_get(sph_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

@@ -24,7 +24,8 @@ SYMBOLS = [
     "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
-    "sph_get_stats", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
+    "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
+    "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
 
@@ -91,6 +92,13 @@ def load():
     lib.sph_download_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.sph_download_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.sph_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.sph_get_bbox.argtypes = [C.c_void_p, _D, _D]
+    lib.sph_set_owned.argtypes = [C.c_void_p, C.c_int64]
+    lib.sph_set_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.sph_scatter_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    lib.sph_refresh_eos.argtypes = [C.c_void_p]
+    lib.sph_dt_candidate.argtypes = [C.c_void_p, _D]
+    lib.sph_set_sink_accel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
     _lib = lib
@@ -194,6 +202,28 @@ class Context:
         self._ck(self.lib.sph_run(self._h, int(nsteps), C.byref(d), C.byref(tt)))
         return d.value, tt.value
 
+    # ---- multi-GPU building blocks ---------------------------------------------------------
+    def set_owned(self, n_owned: int):
+        self._ck(self.lib.sph_set_owned(self._h, int(n_owned)))
+
+    def set_rank(self, rank: int, nranks: int):
+        self._ck(self.lib.sph_set_rank(self._h, int(rank), int(nranks)))
+
+    def scatter_field_dev(self, name: str, first: int, count: int, dev_ptr: int):
+        self._ck(self.lib.sph_scatter_field_dev(self._h, FIELDS.index(name), int(first), int(count), C.c_void_p(int(dev_ptr))))
+
+    def refresh_eos(self):
+        self._ck(self.lib.sph_refresh_eos(self._h))
+
+    def dt_candidate(self) -> float:
+        d = C.c_double(0)
+        self._ck(self.lib.sph_dt_candidate(self._h, C.byref(d)))
+        return d.value
+
+    def set_sink_accel(self, ax, ay, az):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (ax, ay, az)]
+        self._ck(self.lib.sph_set_sink_accel(self._h, a[0].size, *[_hp(v) for v in a]))
+
     # ---- read-back -----------------------------------------------------------------------
     def field(self, name: str) -> np.ndarray:
         out = np.zeros(self.n)
@@ -211,6 +241,11 @@ class Context:
         s = Stats()
         self._ck(self.lib.sph_get_stats(self._h, C.byref(s)))
         return s
+
+    def bbox(self):
+        lo = (C.c_double * 3)(); hi = (C.c_double * 3)()
+        self._ck(self.lib.sph_get_bbox(self._h, lo, hi))
+        return np.array(lo[:]), np.array(hi[:])
 
     def timing(self, on: bool):
         self._ck(self.lib.sph_timing_enable(self._h, 1 if on else 0))

@@ -148,7 +148,22 @@ __global__ __launch_bounds__(256) void unpermute(const double *__restrict__ src,
     if (i < n) dst[orig[i]] = src[i];
 }
 
+// dst[slot] = vals[orig[slot] - first] for the slots whose original id lies in [first, first+count)
+__global__ __launch_bounds__(256) void scatter_by_id(double *__restrict__ dst, const int32_t *__restrict__ orig,
+                                                     const double *__restrict__ vals, int64_t n, int64_t first, int64_t count) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = (int64_t)orig[i] - first;
+    if (id >= 0 && id < count) dst[i] = vals[id];
+}
+
 }  // namespace
+
+hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals) {
+    if (c->n <= 0 || count <= 0) return hipSuccess;
+    scatter_by_id<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(field, c->orig, vals, c->n, first, count);
+    return hipGetLastError();
+}
 
 hipError_t grid_sort_tmp_bytes(int64_t n, size_t *bytes) {
     size_t b = 0;
@@ -200,6 +215,7 @@ int grid_rebuild(sph_ctx *c) {
         return SPH_ERR_NONFINITE;
     }
     const double *bb = c->h_pinned;
+    for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
     GridDesc g{};
     const double edge = 2.0 * c->p.h * (1.0 + 1e-6);
     g.inv_edge = 1.0 / edge;

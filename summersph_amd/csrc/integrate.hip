@@ -69,10 +69,12 @@ __global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict_
                                                        const double *__restrict__ ay, const double *__restrict__ az,
                                                        const double *__restrict__ u, const double *__restrict__ du,
                                                        const double *__restrict__ cs, double h, int64_t n,
-                                                       double *__restrict__ part) {
+                                                       double *__restrict__ part, const int32_t *__restrict__ orig,
+                                                       int32_t n_owned) {
     __shared__ double sm[DT_BLOCK / WAVE];
     double mn = INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
+        if (orig[i] >= n_owned) continue;                     // ghosts are timed by their owners
         const double v2 = vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i];
         const double a2 = ax[i] * ax[i] + ay[i] * ay[i] + az[i] * az[i];
         const double c1 = sqrt(v2 / a2);                      // [F]:846
@@ -107,7 +109,25 @@ __global__ void dt_final(const double *__restrict__ part, int nblocks, double dt
     }
 }
 
+// multi-GPU: only the local candidate, the launcher reduces it over ranks and applies [F]:855-858
+__global__ void dt_candidate_only(const double *__restrict__ part, int nblocks, double dt_scale, double *__restrict__ dtbuf) {
+    double mn = INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 64) mn = fmin(mn, part[b]);
+    mn = wave_min(mn);
+    if (threadIdx.x == 0) dtbuf[2] = mn * dt_scale;
+}
+
 }  // namespace
+
+hipError_t launch_dt_partial_only(sph_ctx *c) {
+    int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
+    if (nb < 1) nb = 1;
+    dt_partial<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_AX],
+                                                           c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_U], c->f[SPH_F_DU],
+                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned);
+    dt_candidate_only<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->d_dt);
+    return hipGetLastError();
+}
 
 hipError_t launch_kick(sph_ctx *c, double dt, bool dt_from_device) {
     KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
@@ -130,7 +150,7 @@ hipError_t launch_next_dt(sph_ctx *c, bool advance_t) {
     if (nb < 1) nb = 1;
     dt_partial<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_AX],
                                                            c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_U], c->f[SPH_F_DU],
-                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part);
+                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned);
     dt_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->p.dt_max, c->p.dt_min, advance_t ? 1 : 0, c->d_dt);
     return hipGetLastError();
 }

@@ -65,12 +65,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
                                                            const int32_t *__restrict__ cell_start, int64_t n,
                                                            double rcut2, int32_t cap, int32_t *__restrict__ nlist,
                                                            int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
-                                                           int32_t *__restrict__ flags) {
+                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ orig,
+                                                           int32_t n_owned) {
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * PAIR_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     int cnt = 0;
-    if (i < n) {
+    if (i < n && orig[i] >= n_owned) ncount[i] = 0;      // ghost: a neighbour only, never a target
+    if (i < n && orig[i] < n_owned) {
         const double4 pi = drec[i];
         int cc[3];
         cell_coords(g, pi.x, pi.y, pi.z, cc);
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
                                                         const double *__restrict__ vx, const double *__restrict__ vy,
                                                         const double *__restrict__ vz, double *__restrict__ rho,
                                                         double *__restrict__ P, double *__restrict__ cs,
-                                                        double *__restrict__ frec) {
+                                                        double *__restrict__ frec, const int32_t *__restrict__ orig,
+                                                        int32_t n_owned) {
     extern __shared__ double lds_w[];
     for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_w[k] = w_tab[k];
     __syncthreads();
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     if ((i & ~(int64_t)63) >= n) return;   // whole wave out of range
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
-    const bool live = i < n;
-    const int self = live ? (int)i : (int)(n - 1);
+    const bool live = i < n && orig[i] < n_owned;   // ghosts keep the rho their owner sent
+    const int self = i < n ? (int)i : (int)(n - 1);
     const double4 pi = drec[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
                                                        const double *__restrict__ sink, int64_t n,
                                                        double *__restrict__ ax, double *__restrict__ ay,
                                                        double *__restrict__ az, double *__restrict__ du,
-                                                       double *__restrict__ dalpha) {
+                                                       double *__restrict__ dalpha, const int32_t *__restrict__ orig,
+                                                       int32_t n_owned) {
     extern __shared__ double lds_dw[];
     for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_dw[k] = dw_tab[k];
     __syncthreads();
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     if ((i & ~(int64_t)63) >= n) return;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
-    const bool live = i < n;
-    const int self = live ? (int)i : (int)(n - 1);
+    const bool live = i < n && orig[i] < n_owned;
+    const int self = i < n ? (int)i : (int)(n - 1);
     const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
     const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/rho^2 c/2 alpha/2 -
     const int cnt = live ? min(ncount[i], cap) : 0;
@@ -342,13 +346,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __global__ __launch_bounds__(SA_BLOCK) void sink_accel_partial(PairConst pc, const double4 *__restrict__ drec, int64_t n,
-                                                               const double *__restrict__ sink, double *__restrict__ part) {
+                                                               const double *__restrict__ sink, double *__restrict__ part,
+                                                               const int32_t *__restrict__ orig, int32_t n_owned) {
     __shared__ double sm[3][SA_BLOCK / WAVE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int s = 0; s < pc.ns; s++) {
         const double sx = sink[0 * MAX_SINKS + s], sy = sink[1 * MAX_SINKS + s], sz = sink[2 * MAX_SINKS + s];
         double b0 = 0.0, b1 = 0.0, b2 = 0.0;
         for (int64_t j = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * SA_BLOCK) {
+            if (orig[j] >= n_owned) continue;                                       // ghosts are summed by their owners
             const double4 p = drec[j];
             const double v0 = p.x - sx, v1 = p.y - sy, v2 = p.z - sz;              // [F]:569
             const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);                   // [F]:570
@@ -432,7 +438,7 @@ int nlist_build(sph_ctx *c) {
         NL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_kernel<<<dim3(pair_blocks(n)), dim3(PAIR_BLOCK), 0, c->stream>>>(
             c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start, n, pc.rcut2, c->nl_cap, c->nlist,
-            c->ncount, c->wave_max, c->d_flags);
+            c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned);
         NL_CHECK(hipGetLastError());
         NL_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         NL_CHECK(hipStreamSynchronize(c->stream));
@@ -455,7 +461,7 @@ hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     density_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->n,
         c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P],
-        c->f[SPH_F_C], c->frec);
+        c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
     return hipGetLastError();
 }
 
@@ -472,7 +478,7 @@ hipError_t launch_forces(sph_ctx *c, const PairConst &pc) {
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
     forces_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
-        c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]);
+        c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
     return hipGetLastError();
 }
 
@@ -481,9 +487,9 @@ hipError_t launch_sink_accel(sph_ctx *c, const PairConst &pc) {
     int nb = (int)std::min<int64_t>((c->n + SA_BLOCK - 1) / SA_BLOCK, c->sink_blocks);
     if (nb < 1) nb = 1;
     sink_accel_partial<<<dim3(nb), dim3(SA_BLOCK), 0, c->stream>>>(pc, reinterpret_cast<const double4 *>(c->drec), c->n,
-                                                                    c->sink, c->sink_part);
+                                                                    c->sink, c->sink_part, c->orig, (int32_t)c->n_owned);
     sink_accel_final<<<dim3(pc.ns), dim3(192), 0, c->stream>>>(c->sink_part, nb, c->sink);
-    if (pc.ns >= 2) sink_sink_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(pc, c->sink);
+    if (pc.ns >= 2 && c->rank == 0) sink_sink_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(pc, c->sink);
     return hipGetLastError();
 }
 

@@ -55,7 +55,9 @@ struct sph_ctx {
     hipStream_t stream = nullptr;
     std::string err;
 
-    int64_t n = 0;        // particles held
+    int64_t n = 0;        // particles held (owned + ghosts)
+    int64_t n_owned = 0;  // original ids [0, n_owned) are this GPU's particles; [n_owned, n) are ghost
+                          // copies of other GPUs' particles: neighbours only, never targets
     int64_t cap = 0;      // allocated particle slots
 
     // cell-sorted struct-of-arrays state + derived + rates (SPH_F_* order)
@@ -70,6 +72,7 @@ struct sph_ctx {
 
     // grid
     sph::GridDesc grid{};
+    double bbox[6] = {0, 0, 0, 0, 0, 0};   // min xyz, max xyz at the last grid build
     uint32_t *keys = nullptr, *keys_alt = nullptr, *vals = nullptr, *vals_alt = nullptr;
     void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     int32_t *cell_start = nullptr; int64_t cell_cap = 0;
@@ -105,6 +108,7 @@ struct sph_ctx {
     int64_t grid_builds = 0, nlist_builds = 0, density_passes = 0, force_passes = 0;
     int64_t device_bytes = 0;
     std::unordered_map<void *, size_t> allocs;   // every device allocation of this context
+    int32_t rank = 0, nranks = 1;   // multi-GPU: only rank 0 adds the sink-sink pair terms before the all-reduce
     bool timing = false;
     sph::TimingSlot tslot[SPH_K_COUNT];
 };
@@ -139,6 +143,8 @@ hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device);
 hipError_t launch_next_dt(sph_ctx *c, bool advance_t);
 hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_original);
 hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n);
+hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals);
+hipError_t launch_dt_partial_only(sph_ctx *c);   // leaves the local candidate (min * dt_scale) in d_dt[2]
 PairConst make_pair_const(const sph_ctx *c);
 
 }  // namespace sph

@@ -11,7 +11,7 @@ module sph_hip_binding
   public :: sph_params_default, sph_ctx_create, sph_ctx_destroy, sph_strerror, sph_last_error, sph_abi_version
   public :: sph_upload, sph_set_sinks, sph_get_sinks, sph_count
   public :: sph_density, sph_forces, sph_kick, sph_drift, sph_next_dt, sph_step, sph_run
-  public :: sph_download_field, sph_download_state, sph_get_stats, sph_synchronize
+  public :: sph_download_field, sph_download_state, sph_get_stats, sph_get_bbox, sph_synchronize
   public :: SPH_OK, SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA
   public :: SPH_F_RHO, SPH_F_P, SPH_F_C, SPH_F_AX, SPH_F_AY, SPH_F_AZ, SPH_F_DU, SPH_F_DALPHA
   public :: c_message
@@ -164,6 +164,13 @@ module sph_hip_binding
       import :: c_int, c_ptr, sph_stats
       type(c_ptr), value :: ctx
       type(sph_stats), intent(out) :: st
+    end function
+
+    ! bounding box of the current positions: what check_bounds (:471-482) needs
+    integer(c_int) function sph_get_bbox(ctx, lo, hi) bind(C, name='sph_get_bbox')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: lo(3), hi(3)
     end function
 
     integer(c_int) function sph_synchronize(ctx) bind(C, name='sph_synchronize')
