@@ -62,10 +62,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000, help="gas particles per GPU")
+    ap.add_argument("--particles", dest="n", type=int, default=1_000_000, help="gas particles per GPU")
     ap.add_argument("--nngb", type=float, default=85.0, help="midplane neighbour target of the IC (mean is ~0.7x)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--reuse-density", action="store_true", help="SPH_FLAG_REUSE_DENSITY (NOT the headline mode)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (host-staged messages)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,8 +80,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo")
+    red_dev = f"cuda:{local_rank}" if (world == 1 or args.backend == "nccl") else "cpu"
 
     # ---- workload: seeded Keplerian disc, fixed h = 2.5 (the [F] path) ------------------------
     # weak scaling: the disc holds n x world particles (same surface density, larger radius) and
@@ -103,7 +111,8 @@ def main():
         mine = {k: v[sel] for k, v in gas.items()}
         mine["gid"] = np.nonzero(sel)[0]
         be = HipBackend(local_rank, flags=flags)
-        sim = DistSim(be, mine, sinks, bounds, group=None)          # device tensors over RCCL
+        # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
+        sim = DistSim(be, mine, sinks, bounds, group=None, comm_device=None if args.backend == "nccl" else "cpu")
         ctx = be.ctx
     del rows, gas
 
@@ -130,9 +139,9 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.timing(False)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     n_loc = torch.tensor([float(sim.n_owned if sim is not None else args.n), float(sim.stats["ghosts"] if sim is not None else 0)],
-                         dtype=torch.float64, device=f"cuda:{local_rank}")
+                         dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         n_max = n_loc.clone()

@@ -156,6 +156,14 @@ int sph_set_rank(sph_ctx *ctx, int32_t rank, int32_t nranks);
 /* field[slot of original id first+k] = d_vals[k], k in [0,count): refreshes ghost rho after the
  * owners' density pass, or ghost v, u, alpha after a kick.                                 */
 int sph_scatter_field_dev(sph_ctx *ctx, int field, int64_t first, int64_t count, const double *d_vals);
+/* several fields at once (one kernel, one synchronisation):
+ * gather : d_out[f*count + k] = field fields[f] of the particle with original id d_ids[k]
+ *          (d_ids == NULL: ids 0..count-1, e.g. all owned particles)
+ * scatter: field fields[f] of original id first+k = d_vals[f*count + k]                      */
+int sph_gather_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int64_t count,
+                          const int64_t *d_ids, double *d_out);
+int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int64_t first, int64_t count,
+                           const double *d_vals);
 /* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */
 int sph_refresh_eos(sph_ctx *ctx);
 /* the local part of get_next_timestep ([F]:845-851): min over OWNED particles * dt_scale;

@@ -24,6 +24,7 @@ SYMBOLS = [
     "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
+    "sph_gather_fields_dev", "sph_scatter_fields_dev",
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
@@ -96,6 +97,8 @@ def load():
     lib.sph_set_owned.argtypes = [C.c_void_p, C.c_int64]
     lib.sph_set_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.sph_scatter_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    lib.sph_gather_fields_dev.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sph_scatter_fields_dev.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_void_p]
     lib.sph_refresh_eos.argtypes = [C.c_void_p]
     lib.sph_dt_candidate.argtypes = [C.c_void_p, _D]
     lib.sph_set_sink_accel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -211,6 +214,16 @@ class Context:
 
     def scatter_field_dev(self, name: str, first: int, count: int, dev_ptr: int):
         self._ck(self.lib.sph_scatter_field_dev(self._h, FIELDS.index(name), int(first), int(count), C.c_void_p(int(dev_ptr))))
+
+    def gather_fields_dev(self, names, count: int, ids_ptr: int, out_ptr: int):
+        """out[f, k] = field names[f] of original id ids[k] (ids_ptr 0: ids 0..count-1); device pointers"""
+        f = (C.c_int32 * len(names))(*[FIELDS.index(n) for n in names])
+        self._ck(self.lib.sph_gather_fields_dev(self._h, len(names), f, int(count), C.c_void_p(int(ids_ptr) or None),
+                                                C.c_void_p(int(out_ptr))))
+
+    def scatter_fields_dev(self, names, first: int, count: int, vals_ptr: int):
+        f = (C.c_int32 * len(names))(*[FIELDS.index(n) for n in names])
+        self._ck(self.lib.sph_scatter_fields_dev(self._h, len(names), f, int(first), int(count), C.c_void_p(int(vals_ptr))))
 
     def refresh_eos(self):
         self._ck(self.lib.sph_refresh_eos(self._h))

@@ -38,7 +38,7 @@ struct DeviceGuard {
 void free_particle_arrays(sph_ctx *c) {
     for (auto &p : c->f) ctx_free(c, p);
     for (auto &p : c->f_alt) ctx_free(c, p);
-    ctx_free(c, c->orig); ctx_free(c, c->orig_alt); ctx_free(c, c->scratch);
+    ctx_free(c, c->orig); ctx_free(c, c->orig_alt); ctx_free(c, c->inv); ctx_free(c, c->scratch);
     ctx_free(c, c->drec); ctx_free(c, c->frec);
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
@@ -54,6 +54,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     for (auto &p : c->f_alt) API_TRY(ctx_alloc(c, &p, (size_t)cap, "state (alt)"));
     API_TRY(ctx_alloc(c, &c->orig, (size_t)cap, "ids"));
     API_TRY(ctx_alloc(c, &c->orig_alt, (size_t)cap, "ids (alt)"));
+    API_TRY(ctx_alloc(c, &c->inv, (size_t)cap, "ids (inverse)"));
     API_TRY(ctx_alloc(c, &c->scratch, (size_t)cap, "scratch"));
     API_TRY(ctx_alloc(c, &c->drec, (size_t)cap * 4, "density records"));
     API_TRY(ctx_alloc(c, &c->frec, (size_t)cap * FREC, "force records"));
@@ -338,6 +339,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
         else API_HIP(hipMemsetAsync(c->f[k], 0, (size_t)n * sizeof(double), c->stream));   // alpha = 0, SUMMER_SPH.f90:681
     }
     API_HIP(launch_iota(c, c->orig, n));
+    API_HIP(launch_iota(c, c->inv, n));
     API_HIP(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = false;
     return SPH_OK;
@@ -478,6 +480,36 @@ int sph_scatter_field_dev(sph_ctx *c, int field, int64_t first, int64_t count, c
     API_HIP(launch_scatter_field(c, c->f[field], first, count, d_vals));
     if (field <= SPH_F_Z || field == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; }
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO) c->eos_valid = false;
+    return SPH_OK;
+}
+
+static bool fields_ok(const sph_ctx *c, int nf, const int *fields, bool for_read) {
+    if (nf < 1 || nf > SPH_F_COUNT || !fields) return false;
+    for (int f = 0; f < nf; f++) {
+        if (fields[f] < 0 || fields[f] >= SPH_F_COUNT) return false;
+        if (for_read && !field_ready(c, fields[f])) return false;
+    }
+    return true;
+}
+
+int sph_gather_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_t count, const int64_t *d_ids, double *d_out) {
+    if (!c || count < 0 || count > c->n || (count > 0 && !d_out)) return SPH_ERR_ARG;
+    if (!fields_ok(c, nf, fields, true)) { c->err = "sph_gather_fields_dev: bad or stale field"; return SPH_ERR_ARG; }
+    DeviceGuard g(c->device);
+    API_HIP(launch_gather_fields(c, nf, fields, d_ids, count, d_out));
+    API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_scatter_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_t first, int64_t count, const double *d_vals) {
+    if (!c || first < 0 || count < 0 || first + count > c->n || (count > 0 && !d_vals)) return SPH_ERR_ARG;
+    if (!fields_ok(c, nf, fields, false)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(launch_scatter_fields(c, nf, fields, first, count, d_vals));
+    for (int f = 0; f < nf; f++) {
+        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; }
+        if (fields[f] <= SPH_F_ALPHA || fields[f] == SPH_F_RHO) c->eos_valid = false;
+    }
     return SPH_OK;
 }
 

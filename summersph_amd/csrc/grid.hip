@@ -123,7 +123,7 @@ struct ReorderArgs {
 
 __global__ __launch_bounds__(256) void reorder(ReorderArgs a, const uint32_t *__restrict__ perm,
                                                const int32_t *__restrict__ orig_in, int32_t *__restrict__ orig_out,
-                                               double *__restrict__ drec, int64_t n) {
+                                               int32_t *__restrict__ inv, double *__restrict__ drec, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = perm[i];
@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void reorder(ReorderArgs a, const uint32_t *__
     for (int k = 0; k < 9; k++) v[k] = a.src[k][s];
 #pragma unroll
     for (int k = 0; k < 9; k++) a.dst[k][i] = v[k];
-    orig_out[i] = orig_in[s];
+    const int32_t id = orig_in[s];
+    orig_out[i] = id;
+    inv[id] = (int32_t)i;                 // original id -> sorted slot
     double4 r = make_double4(v[SPH_F_X], v[SPH_F_Y], v[SPH_F_Z], v[SPH_F_M]);
     reinterpret_cast<double4 *>(drec)[i] = r;
 }
@@ -157,7 +159,49 @@ __global__ __launch_bounds__(256) void scatter_by_id(double *__restrict__ dst, c
     if (id >= 0 && id < count) dst[i] = vals[id];
 }
 
+struct FieldPtrs {
+    double *p[SPH_F_COUNT];
+    int32_t nf;
+};
+
+// out[f][k] = field_f[slot of original id ids[k]]   (ids == nullptr: ids[k] = k)
+__global__ __launch_bounds__(256) void gather_by_id(FieldPtrs fp, const int32_t *__restrict__ inv,
+                                                    const int64_t *__restrict__ ids, int64_t count,
+                                                    double *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int32_t slot = inv[ids ? ids[k] : k];
+    for (int f = 0; f < fp.nf; f++) out[(size_t)f * count + k] = fp.p[f][slot];
+}
+
+// field_f[slot of original id first+k] = vals[f][k]
+__global__ __launch_bounds__(256) void scatter_many_by_id(FieldPtrs fp, const int32_t *__restrict__ inv, int64_t first,
+                                                          int64_t count, const double *__restrict__ vals) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int32_t slot = inv[first + k];
+    for (int f = 0; f < fp.nf; f++) fp.p[f][slot] = vals[(size_t)f * count + k];
+}
+
 }  // namespace
+
+hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out) {
+    if (count <= 0 || nf <= 0) return hipSuccess;
+    FieldPtrs fp{};
+    fp.nf = nf;
+    for (int f = 0; f < nf; f++) fp.p[f] = c->f[fields[f]];
+    gather_by_id<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->inv, ids, count, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals) {
+    if (count <= 0 || nf <= 0) return hipSuccess;
+    FieldPtrs fp{};
+    fp.nf = nf;
+    for (int f = 0; f < nf; f++) fp.p[f] = c->f[fields[f]];
+    scatter_many_by_id<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->inv, first, count, vals);
+    return hipGetLastError();
+}
 
 hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals) {
     if (c->n <= 0 || count <= 0) return hipSuccess;
@@ -258,7 +302,7 @@ int grid_rebuild(sph_ctx *c) {
     // ---- reorder state into sorted slots --------------------------------------------------
     ReorderArgs ra;
     for (int k = 0; k < 9; k++) { ra.src[k] = c->f[k]; ra.dst[k] = c->f_alt[k]; }
-    reorder<<<dim3(gb), dim3(256), 0, st>>>(ra, c->vals_alt, c->orig, c->orig_alt, c->drec, n);
+    reorder<<<dim3(gb), dim3(256), 0, st>>>(ra, c->vals_alt, c->orig, c->orig_alt, c->inv, c->drec, n);
     GR_CHECK(hipGetLastError());
     for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
     std::swap(c->orig, c->orig_alt);

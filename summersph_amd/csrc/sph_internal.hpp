@@ -64,6 +64,7 @@ struct sph_ctx {
     double *f[SPH_F_COUNT] = {};
     double *f_alt[9] = {};           // ping-pong targets for the 9 state fields on reorder
     int32_t *orig = nullptr, *orig_alt = nullptr;   // sorted slot -> original index
+    int32_t *inv = nullptr;                         // original index -> sorted slot
     double *scratch = nullptr;       // n doubles (un-permute on download)
 
     // gather records (array-of-structs: one particle = one or few cache lines)
@@ -144,6 +145,8 @@ hipError_t launch_next_dt(sph_ctx *c, bool advance_t);
 hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_original);
 hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n);
 hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals);
+hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out);
+hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals);
 hipError_t launch_dt_partial_only(sph_ctx *c);   // leaves the local candidate (min * dt_scale) in d_dt[2]
 PairConst make_pair_const(const sph_ctx *c);
 

@@ -15,10 +15,10 @@ particles that lie within 2h of its own particles' bounding box.  Per force eval
   candidate is min-reduced and the reference's dt rule ([F]:855-858) is applied on every rank.
 
 torch.distributed carries every exchange: backend "nccl" (= RCCL over xGMI; every pair of GPUs has
-a direct link, so the point-to-point halo messages do not share links) on a GPU node, "gloo" for the
-CPU tests.  The arithmetic is done by a *backend object*: `HipBackend` (the C ABI, device memory)
-in production; tests plug in an oracle-based backend to exercise this orchestration on CPUs.
-Nothing in this module computes physics.
+a direct link, so the point-to-point halo messages of different pairs do not share links) on a GPU
+node, "gloo" for the CPU tests.  The arithmetic is done by a *backend object*: `HipBackend` (the
+C ABI, device memory) in production; tests plug in an oracle-based backend to exercise this
+orchestration on CPUs.  Nothing in this module computes physics.
 """
 from __future__ import annotations
 
@@ -30,7 +30,12 @@ STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
 
 
 class HipBackend:
-    """The C-ABI context as seen by the orchestrator.  Tensors are float64 on `device`."""
+    """The C-ABI context as seen by the orchestrator.  Tensors are float64 on `device`.
+
+    The library runs on its own HIP stream, torch on its current stream: every hand-over of a torch
+    buffer to the library is preceded by torch.cuda.synchronize (torch's caching allocator may recycle
+    memory that queued torch kernels still read), and every library call that fills a buffer
+    synchronises its stream before returning."""
 
     def __init__(self, device_index: int = 0, **param_overrides):
         from . import capi
@@ -47,28 +52,29 @@ class HipBackend:
     def set_rank(self, rank, nranks):
         self.ctx.set_rank(rank, nranks)
 
-    def upload(self, fields, n_owned):
-        fields = [f.contiguous() for f in fields]
-        self.n = int(fields[0].numel())
+    def upload(self, state: torch.Tensor, n_owned: int):
+        """state: [9, n] (rows in STATE order), owned particles first, then ghosts"""
+        state = state.contiguous()
+        self.n = int(state.shape[1])
         self.n_owned = int(n_owned)
         torch.cuda.synchronize(self.device)
-        self.ctx.upload_dev(self.n, [f.data_ptr() for f in fields])
+        self.ctx.upload_dev(self.n, [state[k].data_ptr() for k in range(9)])
         self.ctx.set_owned(self.n_owned)
 
-    def field(self, name):
-        out = torch.empty(self.n, dtype=torch.float64, device=self.device)
-        if self.n:
-            # the library works on its own HIP stream: torch's caching allocator may hand out memory that
-            # earlier torch kernels (still queued on torch's stream) read from -> drain torch first
+    def gather(self, names, ids: torch.Tensor | None = None, count: int | None = None) -> torch.Tensor:
+        """[len(names), count] values of the particles with original ids `ids` (None: 0..count-1)"""
+        count = int(ids.numel()) if ids is not None else int(count)
+        out = torch.empty((len(names), count), dtype=torch.float64, device=self.device)
+        if count:
             torch.cuda.synchronize(self.device)
-            self.ctx.field_dev(name, out.data_ptr(), self.n)
+            self.ctx.gather_fields_dev(names, count, ids.data_ptr() if ids is not None else 0, out.data_ptr())
         return out
 
-    def scatter(self, name, first, vals):
+    def scatter(self, names, first: int, vals: torch.Tensor):
         vals = vals.contiguous()
-        torch.cuda.synchronize(self.device)
         if vals.numel():
-            self.ctx.scatter_field_dev(name, first, vals.numel(), vals.data_ptr())
+            torch.cuda.synchronize(self.device)
+            self.ctx.scatter_fields_dev(names, first, vals.shape[1], vals.data_ptr())
 
     def set_sinks(self, sinks):
         self.ctx.set_sinks(sinks)
@@ -124,19 +130,19 @@ class DistSim:
         self.h = float(h if h is not None else backend.params.h)
         self.bounds = torch.as_tensor(np.asarray(bounds, dtype=np.float64), device=self.dev)
         self.migrate = migrate
-        be = self.be
-        be.set_rank(self.rank, self.P)
-        self.owned = [torch.as_tensor(np.ascontiguousarray(gas.get(k, np.zeros_like(gas["x"])), dtype=np.float64),
-                                      device=self.dev) for k in STATE]
-        n = self.owned[0].numel()
+        backend.set_rank(self.rank, self.P)
+        n = int(np.asarray(gas["x"]).size)
+        rows = [np.ascontiguousarray(gas[k] if k in gas and gas[k] is not None else np.zeros(n), dtype=np.float64) for k in STATE]
+        self.owned = torch.as_tensor(np.stack(rows), device=self.dev)            # [9, n_owned]
         gid = gas.get("gid")
         self.gid = torch.as_tensor(np.asarray(gid if gid is not None else np.arange(n), dtype=np.int64), device=self.dev)
         self.n_owned = n
         self.sinks = {k: np.array(v, dtype=np.float64, copy=True) for k, v in sinks.items()}
-        be.set_sinks(self.sinks)
+        backend.set_sinks(self.sinks)
         self.pos_dirty = True     # ghosts (and the backend's arrays) do not match the owned positions
         self.vel_dirty = False    # ghost v, u, alpha are older than their owners'
-        self.send_idx = [None] * self.P      # per peer: indices (into owned order) of the particles it ghosts
+        self.in_backend = False   # the current owned state lives in the backend (self.owned is stale)
+        self.send_idx = [None] * self.P      # per peer: original ids of my particles it holds as ghosts
         self.ghost_first = [0] * self.P      # per peer: first original id of its ghosts in my context
         self.ghost_count = [0] * self.P
         self.t = 0.0
@@ -164,9 +170,9 @@ class DistSim:
         self.stats["exchanges"] += 1
         return [r.to(self.dev) if r is not None else None for r in recv]
 
-    def _counts_matrix(self, my_counts: list) -> torch.Tensor:
-        """all-gather of each rank's per-peer send counts -> [P, P] (row = sender)"""
-        mine = torch.tensor(my_counts, dtype=torch.int64, device=self.comm_dev)
+    def _all_gather_rows(self, row: torch.Tensor) -> torch.Tensor:
+        """every rank contributes one 1-D tensor of equal length -> [P, len] on the host"""
+        mine = row.to(self.comm_dev).contiguous()
         out = [torch.empty_like(mine) for _ in range(self.P)]
         dist.all_gather(out, mine, group=self.group)
         return torch.stack(out).cpu()
@@ -179,87 +185,82 @@ class DistSim:
 
     # ---- domain bookkeeping -----------------------------------------------------------------------
     def _pull_owned(self):
-        """owned state out of the backend (upload order = owned first)"""
-        self.owned = [self.be.field(k)[: self.n_owned].clone() for k in STATE]
+        """owned state out of the backend: one fused gather of the 9 state fields"""
+        self.owned = self.be.gather(STATE, None, self.n_owned)
+        self.in_backend = False
 
     def _migrate(self):
         x = self.owned[0]
-        dest = torch.bucketize(x, self.bounds, right=True) if self.P > 1 else torch.zeros_like(x, dtype=torch.int64)
-        stay = dest == self.rank
-        send, counts = [None] * self.P, [0] * self.P
-        payload = torch.stack(self.owned + [self.gid.to(torch.float64)])     # [10, n]; gid < 2^53 is exact
+        dest = torch.bucketize(x, self.bounds, right=True)
+        counts = torch.bincount(dest, minlength=self.P)
+        cm = self._all_gather_rows(counts)                      # [P, P], row = sender, host
+        mine_out = cm[self.rank].clone(); mine_out[self.rank] = 0
+        incoming = cm[:, self.rank].clone(); incoming[self.rank] = 0
+        moved = int(cm.sum() - cm.diag().sum())
+        if moved == 0:
+            return
+        payload = torch.cat([self.owned, self.gid.to(torch.float64)[None, :]])     # [10, n]; gid < 2^53 is exact
+        send = [None] * self.P
         for q in range(self.P):
-            if q == self.rank:
-                continue
-            idx = torch.nonzero(dest == q).flatten()
-            counts[q] = int(idx.numel())
-            if counts[q]:
-                send[q] = payload[:, idx]
-        cm = self._counts_matrix(counts)
-        recv = self._p2p(send, [int(cm[q, self.rank]) for q in range(self.P)], 10)
-        moved = int(cm.sum())
-        if moved:
-            parts = [payload[:, stay]] + [r for r in recv if r is not None]
-            allp = torch.cat(parts, dim=1)
-            self.owned = [allp[k].contiguous() for k in range(9)]
-            self.gid = allp[9].to(torch.int64)
-            self.n_owned = int(allp.shape[1])
+            if int(mine_out[q]):
+                send[q] = payload[:, dest == q]
+        recv = self._p2p(send, [int(v) for v in incoming], 10)
+        parts = [payload[:, dest == self.rank]] + [r for r in recv if r is not None]
+        allp = torch.cat(parts, dim=1)
+        self.owned = allp[:9].contiguous()
+        self.gid = allp[9].to(torch.int64)
+        self.n_owned = int(allp.shape[1])
         self.stats["migrated"] += moved
 
     def _exchange_ghosts(self):
         """steps 2-4 of the module docstring: who needs which of my particles, ship them, upload"""
-        x, y, z = self.owned[0], self.owned[1], self.owned[2]
+        pos = self.owned[:3]
         if self.n_owned:
-            bb = [float(x.min()), float(y.min()), float(z.min()), float(x.max()), float(y.max()), float(z.max())]
+            bb = torch.cat([pos.min(dim=1).values, pos.max(dim=1).values])
         else:
-            bb = [np.inf, np.inf, np.inf, -np.inf, -np.inf, -np.inf]
-        t = torch.tensor(bb, dtype=torch.float64, device=self.comm_dev)
-        boxes = [torch.empty_like(t) for _ in range(self.P)]
-        dist.all_gather(boxes, t, group=self.group)
-        boxes = torch.stack(boxes).cpu().numpy()
+            bb = torch.tensor([np.inf] * 3 + [-np.inf] * 3, dtype=torch.float64, device=self.dev)
+        boxes = self._all_gather_rows(bb).numpy()                # [P, 6] on the host
         r = 2.0 * self.h * (1.0 + 1e-9)
+        me_lo, me_hi = boxes[self.rank, :3], boxes[self.rank, 3:]
         send, counts = [None] * self.P, [0] * self.P
-        payload = torch.stack(self.owned)
         for q in range(self.P):
             self.send_idx[q] = None
-            if q == self.rank:
+            if q == self.rank or not np.all(np.isfinite(boxes[q])) or not np.all(np.isfinite(boxes[self.rank])):
                 continue
             lo, hi = boxes[q, :3] - r, boxes[q, 3:] + r
-            if not np.all(np.isfinite(lo)):
+            if np.any(me_hi < lo) or np.any(me_lo > hi):          # boxes do not touch: nothing to send
                 continue
-            m = (x >= lo[0]) & (x <= hi[0]) & (y >= lo[1]) & (y <= hi[1]) & (z >= lo[2]) & (z <= hi[2])
-            idx = torch.nonzero(m).flatten()
+            lo_t = torch.as_tensor(lo, device=self.dev)[:, None]
+            hi_t = torch.as_tensor(hi, device=self.dev)[:, None]
+            idx = torch.nonzero(((pos >= lo_t) & (pos <= hi_t)).all(dim=0)).flatten()
             counts[q] = int(idx.numel())
             if counts[q]:
                 self.send_idx[q] = idx
-                send[q] = payload[:, idx]
-        cm = self._counts_matrix(counts)
+                send[q] = self.owned[:, idx]
+        cm = self._all_gather_rows(torch.tensor(counts, dtype=torch.int64, device=self.dev))
         rc = [int(cm[q, self.rank]) for q in range(self.P)]
         recv = self._p2p(send, rc, 9)
         first = self.n_owned
-        parts = [payload]
+        parts = [self.owned]
         for q in range(self.P):
             self.ghost_first[q], self.ghost_count[q] = first, rc[q]
             if recv[q] is not None:
                 parts.append(recv[q])
             first += rc[q]
-        allp = torch.cat(parts, dim=1)
+        allp = torch.cat(parts, dim=1) if len(parts) > 1 else self.owned
         self.stats["ghosts"] = int(allp.shape[1]) - self.n_owned
-        self.be.upload([allp[k].contiguous() for k in range(9)], self.n_owned)
+        self.be.upload(allp, self.n_owned)
+        self.in_backend = True
 
     def _refresh_ghost_fields(self, names):
         """ship the listed fields of the particles my peers hold as ghosts; scatter what I receive"""
         if self.P == 1:
             return
-        mine = [self.be.field(k)[: self.n_owned] for k in names]
-        stack = torch.stack(mine)
-        send = [stack[:, idx] if idx is not None else None for idx in self.send_idx]
+        send = [self.be.gather(names, idx) if idx is not None else None for idx in self.send_idx]
         recv = self._p2p(send, self.ghost_count, len(names))
         for q in range(self.P):
-            if recv[q] is None:
-                continue
-            for k, name in enumerate(names):
-                self.be.scatter(name, self.ghost_first[q], recv[q][k])
+            if recv[q] is not None:
+                self.be.scatter(names, self.ghost_first[q], recv[q])
 
     # ---- the hot path, distributed -----------------------------------------------------------------
     def evaluate(self):
@@ -267,13 +268,14 @@ class DistSim:
         be = self.be
         if self.pos_dirty:
             if self.P > 1:
-                if be.n:                       # not the first call: the current state lives in the backend
+                if self.in_backend:
                     self._pull_owned()
                 if self.migrate:
                     self._migrate()
                 self._exchange_ghosts()
-            elif be.n == 0:                    # single rank: upload once, everything stays on the device
+            elif not self.in_backend:          # single rank: upload once, everything stays on the device
                 be.upload(self.owned, self.n_owned)
+                self.in_backend = True
             be.density()
             self._refresh_ghost_fields(["rho"])
             if self.P > 1:
@@ -294,7 +296,9 @@ class DistSim:
 
     def next_dt(self, dt: float) -> float:
         """get_next_timestep, [F]:851-859, with the candidate min-reduced over ranks"""
-        cand = float(self._allreduce([self.be.dt_candidate()], dist.ReduceOp.MIN)[0]) if self.P > 1 else self.be.dt_candidate()
+        cand = self.be.dt_candidate()
+        if self.P > 1:
+            cand = float(self._allreduce([cand], dist.ReduceOp.MIN)[0])
         p = self.be.params
         if cand > 2 * dt and 1.5 * dt < p.dt_max:
             return 1.5 * dt
@@ -322,8 +326,9 @@ class DistSim:
 
     def gather_state(self) -> dict:
         """owned state + gid of this rank as numpy (for checks and saves)"""
-        if self.be.n:
+        if self.in_backend:
             self._pull_owned()
+            self.in_backend = True      # the backend copy stays valid
         out = {k: self.owned[i].cpu().numpy() for i, k in enumerate(STATE)}
         out["gid"] = self.gid.cpu().numpy()
         return out

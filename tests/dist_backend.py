@@ -31,22 +31,24 @@ class OracleBackend:
     def set_rank(self, rank, nranks):
         self.rank, self.nranks = rank, nranks
 
-    def upload(self, fields, n_owned):
-        self.n, self.n_owned = int(fields[0].numel()), int(n_owned)
-        for k, t in zip(self.STATE, fields):
-            self.f[k] = np.ascontiguousarray(t.cpu().numpy(), dtype=np.float64).copy()
+    def upload(self, state, n_owned):
+        self.n, self.n_owned = int(state.shape[1]), int(n_owned)
+        for i, k in enumerate(self.STATE):
+            self.f[k] = np.ascontiguousarray(state[i].cpu().numpy(), dtype=np.float64).copy()
         for k in "rho P c ax ay az du dalpha".split():
             self.f[k] = np.zeros(self.n)
         self._ghost_rho = None
 
-    def field(self, name):
-        return torch.from_numpy(self.f[name].copy())
+    def gather(self, names, ids=None, count=None):
+        idx = np.arange(int(count)) if ids is None else ids.cpu().numpy()
+        return torch.from_numpy(np.stack([self.f[k][idx] for k in names]))
 
-    def scatter(self, name, first, vals):
+    def scatter(self, names, first, vals):
         v = vals.cpu().numpy()
-        self.f[name][first:first + v.size] = v
-        if name == "rho":      # ghosts keep the rho their owner sent (the HIP kernels never overwrite it)
-            self._ghost_rho = self.f["rho"][self.n_owned:].copy()
+        for i, name in enumerate(names):
+            self.f[name][first:first + v.shape[1]] = v[i]
+            if name == "rho":  # ghosts keep the rho their owner sent (the HIP kernels never overwrite it)
+                self._ghost_rho = self.f["rho"][self.n_owned:].copy()
 
     def set_sinks(self, s):
         self.s = {k: np.array(s[k], dtype=np.float64, copy=True) for k in "x y z vx vy vz m".split()}
