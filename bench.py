@@ -156,6 +156,14 @@ def main():
         f_ms, f_cnt = kt["forces"]
         f_avg_s = f_ms / max(f_cnt, 1) * 1e-3
         n_slots = st.n                                      # owned + ghosts held by rank 0's context
+        # HBM traffic of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 on
+        # itself); only quoted when it was measured on this very workload size
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_forces_traffic.json")
+        if os.path.exists(tf):
+            rec = json.load(open(tf))
+            if rec.get("workload_particles") == args.n and world == 1:
+                traffic = rec["traffic_bytes_per_launch"]
         alg_bytes = BYTES["forces"] * args.n
         achieved = alg_bytes / f_avg_s / 1e9
         pairs_per_step = 2 * 2 * st.nlist_mean * args.n     # density + force visits, 2 evaluations
@@ -177,7 +185,7 @@ def main():
                        "max_owned_per_gpu": int(n_max[0].item()), "max_ghosts_per_gpu": int(n_max[1].item()),
                        "rank0_slots": int(n_slots)},
             "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
                          "note": "compulsory HBM traffic is tiny for this path; the pair loop is fp64-VALU / "
                                  "gather bound, see valu_fp64"},

@@ -18,8 +18,8 @@ _D = C.POINTER(C.c_double)
 
 def build() -> str:
     path = os.path.join(_HERE, "liborc.so")
-    src = os.path.join(_HERE, "sph_oracle.c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sph_oracle.c", "sph_oracle_v.c")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "liborc.so"], check=True, stdout=subprocess.DEVNULL)
     return path
 

@@ -101,7 +101,54 @@ def thin_ring(n: int, seed: int = 404, nngb: float = 60.0, h: float = H_REF, rel
     return out
 
 
+def keplerian_disc_var(n: int, seed: int = 303, r_in: float = 10.0, eta: float = 1.2, h_mid: float = H_REF,
+                       scale_height: float = 2.5, m_disc: float = 0.01, m_star: float = 1.0, u0: float = 0.25,
+                       alpha0: float = 0.1, h_cap: float = 8.0, with_sink: bool = True) -> np.ndarray:
+    """Variable-h disc in the 10-column format of the reference's variable-h reader
+    ("SUMMER_SPH - Variable.f90":782): x y z vx vy vz u m alpha h.  h_i = eta (m / rho_est)^(1/3)
+    with the analytic density estimate of the vertical Gaussian; the surface density is chosen so
+    that h = h_mid in the midplane whatever n is.  (BASELINE config 3.)"""
+    rng = np.random.default_rng(seed)
+    n0 = (eta / h_mid) ** 3                                   # midplane number density
+    sigma_n = n0 * np.sqrt(2.0 * np.pi) * scale_height
+    r_out = np.sqrt(n / (np.pi * sigma_n) + r_in ** 2)
+    r = np.sqrt(rng.uniform(r_in ** 2, r_out ** 2, size=n))
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=n)
+    z = rng.normal(0.0, scale_height, size=n)
+    vk = np.sqrt(G_DP * m_star / r)
+    out = np.zeros((n + (1 if with_sink else 0), 10))
+    out[:n, 0] = r * np.cos(phi)
+    out[:n, 1] = r * np.sin(phi)
+    out[:n, 2] = z
+    out[:n, 3] = -vk * np.sin(phi)
+    out[:n, 4] = vk * np.cos(phi)
+    out[:n, 6] = u0
+    out[:n, 7] = m_disc / n
+    out[:n, 8] = alpha0
+    nz = n0 * np.exp(-0.5 * (z / scale_height) ** 2)
+    out[:n, 9] = np.minimum(eta * nz ** (-1.0 / 3.0), h_cap)
+    if with_sink:
+        out[n, 7] = m_star
+    return out
+
+
 def split_rows(rows: np.ndarray):
+    if rows.shape[1] >= 10:
+        return split_rows_var(rows)
+    return _split_rows_fixed(rows)
+
+
+def split_rows_var(rows: np.ndarray):
+    """10-column ingest of the variable-h reference (Variable.f90:793-843): alpha and h come from
+    columns 9 and 10, sinks get radius 5."""
+    gas, sinks = _split_rows_fixed(rows[:, :8], sink_radius=5.0)
+    is_sink = rows[:, 6] == 0.0
+    gas["alpha"] = rows[~is_sink, 8].copy()
+    gas["h"] = rows[~is_sink, 9].copy()
+    return gas, sinks
+
+
+def _split_rows_fixed(rows: np.ndarray, sink_radius: float = 3.5):
     """Gas/sink split exactly as the reference's reader does it (SUMMER_SPH.f90:658-707):
     u != 0 -> gas (alpha starts at 0), u == 0 -> sink (radius 3.5); with no sink row a single
     massless dummy sink at the origin is created.  Returns (gas dict, sink dict)."""
@@ -118,7 +165,7 @@ def split_rows(rows: np.ndarray):
         sinks = {
             "x": s[:, 0].copy(), "y": s[:, 1].copy(), "z": s[:, 2].copy(),
             "vx": s[:, 3].copy(), "vy": s[:, 4].copy(), "vz": s[:, 5].copy(),
-            "m": s[:, 7].copy(), "radius": np.full(s.shape[0], 3.5),
+            "m": s[:, 7].copy(), "radius": np.full(s.shape[0], sink_radius),
         }
     else:
         z1 = np.zeros(1)
