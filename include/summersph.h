@@ -61,9 +61,19 @@ typedef struct sph_params {
     double dt_max;       /* (double)0.1f    ([F]:855)                                     */
     double dt_min;       /* (double)0.0001f ([F]:857)                                     */
     double bounding_size;/* 1500   ([F]:11), used by sph_cull_bounds                      */
+    /* variable-h path only ("SUMMER_SPH - Variable.f90", "[V]"; flags & SPH_FLAG_VARIABLE_H)  */
+    double eta;          /* h = eta (m/rho)^(1/3) target of calc_smoothing ([V]:527)          */
+    double h_tol;        /* convergence_criteria of calc_smoothing ([V]:529)                  */
+    double h_max_length; /* max_length ([V]:528)                                              */
+    double h_min_length; /* (double)0.01f ([V]:528)                                           */
+    double h_iter_cap;   /* 10.0 ([V]:529)                                                    */
 } sph_params;
 
 /* flags */
+#define SPH_FLAG_VARIABLE_H 2   /* per-particle smoothing length, grad-h terms and the leaf-box
+                                   neighbour rule of the reference's variable-h variant [V]:
+                                   kernel normalised with h_i and REAL(4) pi, nq = 2500, Omega,
+                                   h update after every step.  Upload h with sph_upload_field. */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
                                     change since the last one (bitwise the same rho); OFF by
                                     default: the reference recomputes it, [F]:896,908 */
@@ -72,6 +82,8 @@ typedef struct sph_params {
 enum sph_field {
     SPH_F_X = 0, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA,
     SPH_F_RHO, SPH_F_P, SPH_F_C, SPH_F_AX, SPH_F_AY, SPH_F_AZ, SPH_F_DU, SPH_F_DALPHA,
+    SPH_F_H,        /* smoothing length (state, variable-h path; [V]:24 s_length)             */
+    SPH_F_OMEGA,    /* grad-h factor (derived, variable-h path; [V]:25 omega)                  */
     SPH_F_COUNT
 };
 
@@ -83,6 +95,8 @@ enum sph_kernel_id {
     SPH_K_FORCES,      /* sink gravity + SPH pair forces + alpha rate                     */
     SPH_K_SINKACC,     /* acceleration of the sinks                                       */
     SPH_K_KICK, SPH_K_DRIFT, SPH_K_DT,
+    SPH_K_LEAF,        /* variable-h: octree leaf boxes (Morton keys, sort, depth)             */
+    SPH_K_UPDATE_H,    /* variable-h: calc_smoothing                                          */
     SPH_K_COUNT
 };
 
@@ -100,6 +114,9 @@ typedef struct sph_stats {
 /* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation
  *      in simulate ([F]:894,901,905,928) ------------------------------------------------ */
 int sph_params_default(sph_params *p);
+/* defaults of the variable-h variant: SPH_FLAG_VARIABLE_H, nq 2500, REAL(4) pi, gamma_m1 =
+ * gamma - 1.0, eta 1.2, h_tol 1e-3, h_max_length 10 (the reference ships no parameters.txt) */
+int sph_params_default_variable(sph_params *p);
 int sph_ctx_create(const sph_params *p, int device, sph_ctx **out);
 int sph_ctx_destroy(sph_ctx *ctx);
 const char *sph_strerror(int status);
@@ -121,6 +138,9 @@ int sph_get_sinks(sph_ctx *ctx, int32_t ns, double *sx, double *sy, double *sz,
                   double *svx, double *svy, double *svz, double *sm,
                   double *sax, double *say, double *saz);
 int64_t sph_count(const sph_ctx *ctx);
+/* one field in the caller's particle order, host or device source (e.g. SPH_F_H after sph_upload) */
+int sph_upload_field(sph_ctx *ctx, int field, const double *host, int64_t n);
+int sph_upload_field_dev(sph_ctx *ctx, int field, const double *d_vals, int64_t n);
 
 /* ---- the hot path ------------------------------------------------------------------- */
 /* create_tree + get_density + get_pressure_and_sound_speed   ([F]:894-897, 398-468)      */
@@ -133,7 +153,9 @@ int sph_kick(sph_ctx *ctx, double dt);
 int sph_drift(sph_ctx *ctx, double dt);
 /* get_next_timestep ([F]:831-860): in/out dt                                             */
 int sph_next_dt(sph_ctx *ctx, double *dt);
-/* one iteration of simulate's loop body, [F]:889-916: density, forces, kick, drift,
+/* variable-h only: calc_smoothing ([V]:515-546) on the neighbour structure of the last evaluation */
+int sph_update_h(sph_ctx *ctx);
+/* one iteration of simulate's loop body, [F]:889-916 (variable-h: [V]:1120-1152 incl. the h update): density, forces, kick, drift,
  * density, forces, kick, t += dt, next dt.  Identical to the unfused call sequence.      */
 int sph_step(sph_ctx *ctx, double *dt, double *t);
 /* nsteps iterations without returning to the host in between (dt stays on the device)    */

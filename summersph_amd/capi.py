@@ -14,13 +14,15 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsummersph_hip.so")
 _D = C.POINTER(C.c_double)
 
-FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha"]
-KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt"]
+FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha", "h", "omega"]
+KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h"]
 FLAG_REUSE_DENSITY = 1
+FLAG_VARIABLE_H = 2
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
-    "sph_params_default", "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
+    "sph_params_default", "sph_params_default_variable", "sph_upload_field", "sph_upload_field_dev", "sph_update_h",
+    "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
     "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
@@ -35,7 +37,8 @@ class Params(C.Structure):
                 ("flags", C.c_int32), ("kernel_pi", C.c_double), ("visc_eps", C.c_double),
                 ("alpha_floor", C.c_double), ("alpha_decay", C.c_double), ("G", C.c_double),
                 ("dt_scale", C.c_double), ("dt_max", C.c_double), ("dt_min", C.c_double),
-                ("bounding_size", C.c_double)]
+                ("bounding_size", C.c_double), ("eta", C.c_double), ("h_tol", C.c_double),
+                ("h_max_length", C.c_double), ("h_min_length", C.c_double), ("h_iter_cap", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -94,6 +97,9 @@ def load():
     lib.sph_download_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.sph_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.sph_get_bbox.argtypes = [C.c_void_p, _D, _D]
+    lib.sph_upload_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.sph_upload_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.sph_update_h.argtypes = [C.c_void_p]
     lib.sph_set_owned.argtypes = [C.c_void_p, C.c_int64]
     lib.sph_set_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.sph_scatter_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
@@ -108,9 +114,12 @@ def load():
     return lib
 
 
-def default_params() -> Params:
+def default_params(variable: bool = False) -> Params:
     p = Params()
-    load().sph_params_default(C.byref(p))
+    if variable:
+        load().sph_params_default_variable(C.byref(p))
+    else:
+        load().sph_params_default(C.byref(p))
     return p
 
 
@@ -124,9 +133,9 @@ def _hp(a):
 class Context:
     """Thin object wrapper over an sph_ctx*.  Arrays are float64 numpy (host) unless a method says _dev."""
 
-    def __init__(self, params: Params | None = None, device: int = 0, **overrides):
+    def __init__(self, params: Params | None = None, device: int = 0, variable: bool = False, **overrides):
         self.lib = load()
-        p = params if params is not None else default_params()
+        p = params if params is not None else default_params(variable)
         for k, v in overrides.items():
             setattr(p, k, v)
         self.params = p
@@ -161,6 +170,18 @@ class Context:
         al = gas.get("alpha")
         al = None if al is None else np.ascontiguousarray(al, dtype=np.float64)
         self._ck(self.lib.sph_upload(self._h, arrs[0].size, *[_hp(a) for a in arrs], _hp(al)))
+        if gas.get("h") is not None and (self.params.flags & FLAG_VARIABLE_H):
+            self.upload_field("h", gas["h"])
+
+    def upload_field(self, name: str, values):
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        self._ck(self.lib.sph_upload_field(self._h, FIELDS.index(name), _hp(a), a.size))
+
+    def upload_field_dev(self, name: str, dev_ptr: int, n: int):
+        self._ck(self.lib.sph_upload_field_dev(self._h, FIELDS.index(name), C.c_void_p(int(dev_ptr)), int(n)))
+
+    def update_h(self):
+        self._ck(self.lib.sph_update_h(self._h))
 
     def upload_dev(self, n: int, ptrs):
         """ptrs: 9 device addresses (ints; alpha may be 0/None), e.g. torch tensors' data_ptr()"""

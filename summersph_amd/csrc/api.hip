@@ -43,6 +43,9 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max);
+    ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
+    ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
+    c->msort_tmp_bytes = 0;
     c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
 }
 
@@ -71,6 +74,19 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     API_TRY(ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list"));
     API_TRY(ctx_alloc(c, &c->ncount, (size_t)cap, "neighbour counts"));
     API_TRY(ctx_alloc(c, &c->wave_max, (size_t)c->nl_waves_cap, "wave max"));
+    if (c->variable) {
+        API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));
+        API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
+        API_TRY(ctx_alloc(c, &c->mkeys, (size_t)cap, "octree keys"));
+        API_TRY(ctx_alloc(c, &c->mkeys_alt, (size_t)cap, "octree keys (alt)"));
+        API_TRY(ctx_alloc(c, &c->mvals, (size_t)cap, "octree vals"));
+        API_TRY(ctx_alloc(c, &c->mvals_alt, (size_t)cap, "octree vals (alt)"));
+        API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
+        size_t mt = 0;
+        API_HIP(varh_sort_tmp_bytes(cap, &mt));
+        c->msort_tmp_bytes = mt;
+        API_TRY(ctx_alloc_bytes(c, &c->msort_tmp, mt ? mt : 1, "octree sort scratch"));
+    }
     c->cap = cap;
     return SPH_OK;
 }
@@ -124,17 +140,23 @@ void resolve_timing(sph_ctx *c) {
 
 int do_density(sph_ctx *c) {
     if (!c->grid_valid) {
+        if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
-        { Timed t(c, SPH_K_NLIST); API_TRY(nlist_build(c)); }
+        if (c->variable) {
+            { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
+            { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
+        } else {
+            Timed t(c, SPH_K_NLIST); API_TRY(nlist_build(c));
+        }
         c->grid_valid = true;
     }
     const PairConst pc = make_pair_const(c);
     Timed t(c, SPH_K_DENSITY);
     if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
-        API_HIP(launch_eos_only(c, pc));
+        API_HIP(c->variable ? launch_eos_only_v(c, pc) : launch_eos_only(c, pc));
     } else {
-        API_HIP(launch_density(c, pc));
+        API_HIP(c->variable ? launch_density_v(c, pc) : launch_density(c, pc));
         c->density_passes++;
     }
     c->rho_valid = true; c->eos_valid = true;
@@ -145,7 +167,7 @@ int do_forces(sph_ctx *c) {
     if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces: call sph_density first"; return SPH_ERR_STATE; }
     const PairConst pc = make_pair_const(c);
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-    { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : launch_forces(c, pc)); }
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -180,6 +202,17 @@ int get_dt(sph_ctx *c, double *dt, double *t) {
     return SPH_OK;
 }
 
+// calc_smoothing (Variable.f90:515-546) on the grid / leaf boxes of the last evaluation
+int do_update_h(sph_ctx *c) {
+    if (!c->variable) { c->err = "sph_update_h: context is not in variable-h mode"; return SPH_ERR_STATE; }
+    if (!c->grid_valid || !c->rho_valid) { c->err = "sph_update_h: needs the density of the current positions"; return SPH_ERR_STATE; }
+    const PairConst pc = make_pair_const(c);
+    { Timed t(c, SPH_K_UPDATE_H); API_HIP(launch_update_h(c, pc)); }
+    // h changed: reaches, neighbour sets, rho all depend on it
+    c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
+    return SPH_OK;
+}
+
 int one_step_device_dt(sph_ctx *c) {
     // SUMMER_SPH.f90:889-916
     API_TRY(do_density(c));
@@ -189,14 +222,18 @@ int one_step_device_dt(sph_ctx *c) {
     API_TRY(do_density(c));
     API_TRY(do_forces(c));
     API_TRY(do_kick(c, 0.0, true));
-    Timed t(c, SPH_K_DT);
-    API_HIP(launch_next_dt(c, true));
+    { Timed t(c, SPH_K_DT); API_HIP(launch_next_dt(c, true)); }
+    if (c->variable) API_TRY(do_update_h(c));          // Variable.f90:1152
     return SPH_OK;
 }
 
 bool field_ready(const sph_ctx *c, int field) {
     if (field <= SPH_F_ALPHA) return true;
-    if (field == SPH_F_RHO) return c->rho_valid;
+    if (field == SPH_F_H) return c->variable;
+    // derived arrays are in the current slot order as long as no re-sort happened since they were
+    // written (a re-sort clears rates_valid)
+    if (field == SPH_F_OMEGA) return c->variable && (c->rho_valid || c->rates_valid);
+    if (field == SPH_F_RHO) return c->rho_valid || c->rates_valid;
     if (field == SPH_F_P || field == SPH_F_C) return c->eos_valid || c->rates_valid;
     return c->rates_valid;
 }
@@ -264,6 +301,19 @@ int sph_params_default(sph_params *p) {
     p->dt_max = (double)0.1f;                 // :855
     p->dt_min = (double)0.0001f;              // :857
     p->bounding_size = 1500.0;                // :11
+    p->eta = 1.2; p->h_tol = 1e-3; p->h_max_length = 10.0;     // variable-h only (no reference defaults exist)
+    p->h_min_length = (double)0.01f;          // Variable.f90:528
+    p->h_iter_cap = 10.0;                     // Variable.f90:529
+    return SPH_OK;
+}
+
+int sph_params_default_variable(sph_params *p) {
+    if (!p) return SPH_ERR_ARG;
+    sph_params_default(p);
+    p->flags = SPH_FLAG_VARIABLE_H;
+    p->nq = 2500;                                        // Variable.f90:8
+    p->kernel_pi = (double)3.1415926535897932f;          // Variable.f90:7 (REAL(4) literal)
+    p->gamma = 1.4; p->gamma_m1 = p->gamma - 1.0;        // Variable.f90:509 computes gamma - 1.0_dp
     return SPH_OK;
 }
 
@@ -279,6 +329,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     sph_ctx *c = new (std::nothrow) sph_ctx();
     if (!c) return SPH_ERR_NOMEM;
     c->p = *p;
+    c->variable = (p->flags & SPH_FLAG_VARIABLE_H) != 0;
     c->device = device;
     DeviceGuard g(device);
     int st = SPH_OK;
@@ -326,7 +377,7 @@ int64_t sph_count(const sph_ctx *c) { return c ? c->n : -1; }
 
 static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMemcpyKind kind) {
     if (!c) return SPH_ERR_ARG;
-    if (n < 0 || n > 2000000000LL) { c->err = "sph_upload: bad n"; return SPH_ERR_ARG; }
+    if (n < 0 || n > (c->variable ? 1000000000LL : 2000000000LL)) { c->err = "sph_upload: bad n"; return SPH_ERR_ARG; }
     for (int k = 0; k < 8; k++)
         if (n > 0 && !src[k]) { c->err = "sph_upload: null array"; return SPH_ERR_ARG; }
     DeviceGuard g(c->device);
@@ -340,6 +391,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     }
     API_HIP(launch_iota(c, c->orig, n));
     API_HIP(launch_iota(c, c->inv, n));
+    if (c->variable) API_HIP(launch_fill(c, c->f[SPH_F_H], c->p.h, n));    // until sph_upload_field(SPH_F_H) sets it
     API_HIP(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = false;
     return SPH_OK;
@@ -459,6 +511,29 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
 }
 
 // ---- multi-GPU building blocks (see summersph_amd/dist.py) ------------------------------------
+
+static int upload_field_impl(sph_ctx *c, int field, const double *src, int64_t n, bool host) {
+    if (!c || field < 0 || field >= SPH_F_COUNT || n != c->n || (n > 0 && !src)) return SPH_ERR_ARG;
+    if ((field == SPH_F_H || field == SPH_F_OMEGA) && !c->variable) { c->err = "field needs SPH_FLAG_VARIABLE_H"; return SPH_ERR_ARG; }
+    if (n == 0) return SPH_OK;
+    DeviceGuard g(c->device);
+    const double *dsrc = src;
+    if (host) {
+        API_HIP(hipMemcpyAsync(c->scratch, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        dsrc = c->scratch;
+    }
+    const int f = field;
+    API_HIP(launch_scatter_fields(c, 1, &f, 0, n, dsrc));
+    API_HIP(hipStreamSynchronize(c->stream));
+    if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) { c->grid_valid = false; c->rho_valid = false; }
+    if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
+    return SPH_OK;
+}
+
+int sph_upload_field(sph_ctx *c, int field, const double *host, int64_t n) { return upload_field_impl(c, field, host, n, true); }
+int sph_upload_field_dev(sph_ctx *c, int field, const double *d_vals, int64_t n) { return upload_field_impl(c, field, d_vals, n, false); }
+
+int sph_update_h(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_update_h(c); }
 
 int sph_set_owned(sph_ctx *c, int64_t n_owned) {
     if (!c || n_owned < 0 || n_owned > c->n) return SPH_ERR_ARG;

@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void cell_table(const uint32_t *__restrict__ k
 }
 
 struct ReorderArgs {
-    const double *src[9];
-    double *dst[9];
+    const double *src[10];
+    double *dst[10];
+    int nf;            // 9 state fields, 10 with the smoothing length (variable-h path)
+    double *prec;      // variable-h: {x,y,z,h} gather record, else nullptr
 };
 
 __global__ __launch_bounds__(256) void reorder(ReorderArgs a, const uint32_t *__restrict__ perm,
@@ -127,11 +129,13 @@ __global__ __launch_bounds__(256) void reorder(ReorderArgs a, const uint32_t *__
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = perm[i];
-    double v[9];
+    double v[10];
 #pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = a.src[k][s];
+    for (int k = 0; k < 10; k++) v[k] = k < a.nf ? a.src[k][s] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) a.dst[k][i] = v[k];
+    for (int k = 0; k < 10; k++)
+        if (k < a.nf) a.dst[k][i] = v[k];
+    if (a.prec) reinterpret_cast<double4 *>(a.prec)[i] = make_double4(v[SPH_F_X], v[SPH_F_Y], v[SPH_F_Z], v[9]);
     const int32_t id = orig_in[s];
     orig_out[i] = id;
     inv[id] = (int32_t)i;                 // original id -> sorted slot
@@ -148,6 +152,11 @@ __global__ __launch_bounds__(256) void unpermute(const double *__restrict__ src,
                                                  double *__restrict__ dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[orig[i]] = src[i];
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double *p, double v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // dst[slot] = vals[orig[slot] - first] for the slots whose original id lies in [first, first+count)
@@ -200,6 +209,12 @@ hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t 
     fp.nf = nf;
     for (int f = 0; f < nf; f++) fp.p[f] = c->f[fields[f]];
     scatter_many_by_id<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->inv, first, count, vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(sph_ctx *c, double *p, double v, int64_t n) {
+    if (n <= 0) return hipSuccess;
+    fill_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(p, v, n);
     return hipGetLastError();
 }
 
@@ -261,7 +276,14 @@ int grid_rebuild(sph_ctx *c) {
     const double *bb = c->h_pinned;
     for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
     GridDesc g{};
-    const double edge = 2.0 * c->p.h * (1.0 + 1e-6);
+    // fixed h: cells of edge 2h.  variable h: edge 2 <h> with a per-cell maximum of h (varh.hip)
+    double edge = 2.0 * (c->variable ? c->h_mean : c->p.h) * (1.0 + 1e-6);
+    if (c->variable) {
+        // keep the cell table below ~2^27 cells: widen the cells if the box is huge compared with <h>
+        double vol = 1.0;
+        for (int a = 0; a < 3; a++) vol *= std::floor((bb[3 + a] - bb[a]) / edge) + 1.0;
+        if (vol > 134217728.0) edge *= std::cbrt(vol / 134217728.0);
+    }
     g.inv_edge = 1.0 / edge;
     double ncell_d = 1.0;
     for (int a = 0; a < 3; a++) {
@@ -286,6 +308,10 @@ int grid_rebuild(sph_ctx *c) {
         ctx_free(c, c->cell_start);
         c->cell_cap = (g.ncells + 1) + (g.ncells + 1) / 4;
         if (ctx_alloc(c, &c->cell_start, (size_t)c->cell_cap, "cell table") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
+        if (c->variable) {
+            ctx_free(c, c->cell_hmax);
+            if (ctx_alloc(c, &c->cell_hmax, (size_t)c->cell_cap, "cell hmax") != SPH_OK) return SPH_ERR_NOMEM;
+        }
     }
 
     // ---- keys, sort, cell table ---------------------------------------------------------
@@ -300,11 +326,14 @@ int grid_rebuild(sph_ctx *c) {
     GR_CHECK(hipGetLastError());
 
     // ---- reorder state into sorted slots --------------------------------------------------
-    ReorderArgs ra;
+    ReorderArgs ra{};
     for (int k = 0; k < 9; k++) { ra.src[k] = c->f[k]; ra.dst[k] = c->f_alt[k]; }
+    ra.nf = 9; ra.prec = nullptr;
+    if (c->variable) { ra.src[9] = c->f[SPH_F_H]; ra.dst[9] = c->f_alt[9]; ra.nf = 10; ra.prec = c->prec; }
     reorder<<<dim3(gb), dim3(256), 0, st>>>(ra, c->vals_alt, c->orig, c->orig_alt, c->inv, c->drec, n);
     GR_CHECK(hipGetLastError());
     for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
+    if (c->variable) std::swap(c->f[SPH_F_H], c->f_alt[9]);
     std::swap(c->orig, c->orig_alt);
     c->grid_builds++;
     return SPH_OK;

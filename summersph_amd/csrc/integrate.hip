@@ -70,7 +70,7 @@ __global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict_
                                                        const double *__restrict__ u, const double *__restrict__ du,
                                                        const double *__restrict__ cs, double h, int64_t n,
                                                        double *__restrict__ part, const int32_t *__restrict__ orig,
-                                                       int32_t n_owned) {
+                                                       int32_t n_owned, const double *__restrict__ hvar) {
     __shared__ double sm[DT_BLOCK / WAVE];
     double mn = INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict_
         const double a2 = ax[i] * ax[i] + ay[i] * ay[i] + az[i] * az[i];
         const double c1 = sqrt(v2 / a2);                      // [F]:846
         const double c2 = u[i] / fabs(du[i]);                 // [F]:847
-        const double c3 = h / sqrt(v2);                       // [F]:848
-        const double c4 = h / (cs[i] + 1.2 * cs[i]);          // [F]:849
+        const double hi = hvar ? hvar[i] : h;                 // per-particle h: Variable.f90:1053-1054
+        const double c3 = hi / sqrt(v2);                      // [F]:848
+        const double c4 = hi / (cs[i] + 1.2 * cs[i]);         // [F]:849
         mn = fmin(fmin(fmin(mn, c1), fmin(c2, c3)), c4);      // fmin skips NaN (0/0 candidates)
     }
     mn = wave_min(mn);
@@ -124,7 +125,8 @@ hipError_t launch_dt_partial_only(sph_ctx *c) {
     if (nb < 1) nb = 1;
     dt_partial<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_AX],
                                                            c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_U], c->f[SPH_F_DU],
-                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned);
+                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned,
+                                                           c->variable ? c->f[SPH_F_H] : nullptr);
     dt_candidate_only<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->d_dt);
     return hipGetLastError();
 }
@@ -150,7 +152,8 @@ hipError_t launch_next_dt(sph_ctx *c, bool advance_t) {
     if (nb < 1) nb = 1;
     dt_partial<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_AX],
                                                            c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_U], c->f[SPH_F_DU],
-                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned);
+                                                           c->f[SPH_F_C], c->p.h, c->n, c->dt_part, c->orig, (int32_t)c->n_owned,
+                                                           c->variable ? c->f[SPH_F_H] : nullptr);
     dt_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->p.dt_max, c->p.dt_min, advance_t ? 1 : 0, c->d_dt);
     return hipGetLastError();
 }

@@ -26,36 +26,13 @@
 // contraction, both rounding-level (measured in tests/test_parity_gpu.py).
 #include <cmath>
 
-#include "sph_internal.hpp"
+#include "pair_common.hpp"
 
 namespace sph {
 
 namespace {
 
 constexpr int PAIR_BLOCK = 256;
-
-__device__ __forceinline__ int xcd_chunk(int b, int nb) {
-    // blocks b, b+8, b+16.. share an XCD (round-robin dispatch): give each XCD one
-    // contiguous run of the cell-sorted particle order so neighbours hit the same L2.
-    const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
-__device__ __forceinline__ void cell_coords(const GridDesc &g, double px, double py, double pz, int cc[3]) {
-    const double p[3] = {px, py, pz};
-    int c[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        int v = (int)((p[a] - g.org[a]) * g.inv_edge);
-        c[a] = min(max(v, 0), g.dim[a] - 1);
-    }
-    cc[0] = c[g.s[0]]; cc[1] = c[g.s[1]]; cc[2] = c[g.s[2]];
-}
-
-__device__ __forceinline__ int wave_max_i32(int v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------
 // neighbour list: every j != i with |x_i - x_j|^2 <= rcut2 (rcut2 a hair above (2h)^2; the
@@ -113,45 +90,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
         wave_max[w] = min(wm, cap);
         if (wm > 0) atomicMax(&flags[1], wm);
     }
-}
-
-// ---- fp64 reciprocal / square root helpers ---------------------------------------------------
-// A full IEEE fp64 division costs ~20 VALU instructions on CDNA4 and the reference's pair term has
-// nine of them.  The kernels use the hardware seed (v_rcp_f64 / v_rsq_f64) plus Newton / Goldschmidt
-// steps instead: results are within ~1 ulp of the correctly rounded quotient, i.e. the same size as
-// the summation-order noise that is there anyway (parity tolerance 1e-13, tests/test_parity_gpu.py).
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(e, r, r);
-    e = fma(-x, r, 1.0);
-    r = fma(e, r, r);
-    return r;
-}
-
-// s = sqrt(x), rs = 1/sqrt(x) for x > 0 (x == 0 gives s = 0, rs = inf-free garbage the caller masks)
-__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &s, double &rs) {
-    const double xs = fmax(x, 1e-300);
-    double y = __builtin_amdgcn_rsq(xs);
-    double g = xs * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    const double d = fma(-g, g, xs);
-    g = fma(d, h, g);
-    s = x > 0.0 ? g : 0.0;
-    rs = h + h;
-}
-
-// lookup_kernel's interpolation, [F]:114-118, table in LDS; returns the un-normalised value.
-// k = min(int(q/dq), nq-1), a = (q - k dq)/dq  are evaluated as q*(1/dq): identical except within
-// an ulp of a table knot, where the (continuous) interpolant changes by O(1e-16).
-__device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double inv_dq, int nq) {
-    const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k;
-    return (1.0 - a) * tab[k] + a * tab[k + 1];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,6 +354,9 @@ PairConst make_pair_const(const sph_ctx *c) {
     pc.G = p.G; pc.gamma = p.gamma; pc.gamma_m1 = p.gamma_m1;
     pc.rcut2 = 4.0 * p.h * p.h * (1.0 + 1e-12);
     pc.ns = c->ns;
+    pc.kernel_pi = p.kernel_pi; pc.eta = p.eta; pc.h_tol = p.h_tol; pc.h_max_length = p.h_max_length;
+    pc.h_min_length = p.h_min_length; pc.h_iter_cap = p.h_iter_cap; pc.dt_scale = p.dt_scale;
+    if (c->variable) pc.visc_eps_h2 = p.visc_eps;        // multiplied by avg_len^2 per pair (Variable.f90:405)
     return pc;
 }
 

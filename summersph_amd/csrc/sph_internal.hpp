@@ -39,6 +39,8 @@ struct PairConst {
     double rcut2;        // (2h)^2 (1 + 1e-12): filter only, the evaluation re-tests q <= 2
     int32_t nq;
     int32_t ns;          // sinks
+    // variable-h path
+    double kernel_pi, eta, h_tol, h_max_length, h_min_length, h_iter_cap, dt_scale;
 };
 
 struct TimingSlot {
@@ -62,7 +64,7 @@ struct sph_ctx {
 
     // cell-sorted struct-of-arrays state + derived + rates (SPH_F_* order)
     double *f[SPH_F_COUNT] = {};
-    double *f_alt[9] = {};           // ping-pong targets for the 9 state fields on reorder
+    double *f_alt[10] = {};          // ping-pong targets for the state fields on reorder (9, +h when variable)
     int32_t *orig = nullptr, *orig_alt = nullptr;   // sorted slot -> original index
     int32_t *inv = nullptr;                         // original index -> sorted slot
     double *scratch = nullptr;       // n doubles (un-permute on download)
@@ -70,6 +72,18 @@ struct sph_ctx {
     // gather records (array-of-structs: one particle = one or few cache lines)
     double *drec = nullptr;          // 4 doubles: x y z m
     double *frec = nullptr;          // FREC doubles: x y z m vx vy vz rho P/rho^2 c alpha 0
+
+    // variable-h path ("SUMMER_SPH - Variable.f90"): extra gather records and the octree leaf boxes
+    bool variable = false;
+    double *prec = nullptr;          // 4 doubles: x y z h        (neighbour-list build)
+    double *lrec = nullptr;          // 4 doubles: leaf centre x y z, reach = 2h + leaf_edge/2 (<0: unresolved)
+    uint64_t *mkeys = nullptr, *mkeys_alt = nullptr;   // octree path keys (3 bits per level, 21 levels)
+    uint32_t *mvals = nullptr, *mvals_alt = nullptr;
+    void *msort_tmp = nullptr; size_t msort_tmp_bytes = 0;
+    double *cell_hmax = nullptr;     // per cell: largest h of its particles
+    double *h_new = nullptr;         // scratch for calc_smoothing
+    double h_max_glob = 0.0, h_mean = 0.0;
+    double root_box[4] = {0, 0, 0, 0};   // octree root centre + edge ([V]:1007-1012)
 
     // grid
     sph::GridDesc grid{};
@@ -144,10 +158,20 @@ hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device);
 hipError_t launch_next_dt(sph_ctx *c, bool advance_t);
 hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_original);
 hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n);
+hipError_t launch_fill(sph_ctx *c, double *p, double v, int64_t n);
 hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals);
 hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out);
 hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals);
-hipError_t launch_dt_partial_only(sph_ctx *c);   // leaves the local candidate (min * dt_scale) in d_dt[2]
+hipError_t launch_dt_partial_only(sph_ctx *c);
+// variable-h path (varh.hip)
+hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
+int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)
+int varh_leaf_build(sph_ctx *c);       // leaf boxes of all particles for the current positions + h
+int varh_nlist_build(sph_ctx *c);
+hipError_t launch_density_v(sph_ctx *c, const PairConst &pc);
+hipError_t launch_eos_only_v(sph_ctx *c, const PairConst &pc);
+hipError_t launch_forces_v(sph_ctx *c, const PairConst &pc);
+hipError_t launch_update_h(sph_ctx *c, const PairConst &pc);   // leaves the local candidate (min * dt_scale) in d_dt[2]
 PairConst make_pair_const(const sph_ctx *c);
 
 }  // namespace sph

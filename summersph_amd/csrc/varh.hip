@@ -1,0 +1,575 @@
+// varh.hip -- the variable-h path: per-particle smoothing length, grad-h terms, the reference's
+// leaf-box neighbour rule and the h update.
+//
+// Replaces (citations: "/root/reference/SUMMER_SPH - Variable.f90", "[V]")
+//   create_tree / build_tree (geometry only)    [V]:999-1020,163-267 -> leaf_keys, leaf_boxes
+//   density_tree_search / get_density (rho, Om) [V]:440-496          -> density_v_kernel
+//   get_pressure_and_sound_speed(gamma)         [V]:502-512          -> density_v_kernel epilogue
+//   SPH_tree_search / get_SPH (grad-h form)     [V]:324-432          -> forces_v_kernel
+//   calc_smoothing                              [V]:515-546          -> update_h_kernel
+//
+// The neighbour rule of [V] is not a sphere test.  The tree walk of a body at
+// x reaches particle j's one-particle leaf iff on every axis |x - c_leaf(j)| < 2 h_j + edge_leaf(j)/2;
+// the kernel then uses the BODY's h (density) or both (forces), and a force pair {a,b} (a > b by
+// particle number) is evaluated iff a's walk reaches b's leaf.  To reproduce that, every particle's
+// leaf box of the reference octree (bbox-midpoint root, edge = largest extent, strict '>' split) is
+// computed here WITHOUT building the tree: the path of a particle down the octree is a 3-bit-per-
+// level key; after a radix sort of those keys a particle's leaf level is 1 + its longest common
+// prefix with its sorted neighbours, and the leaf centre follows from replaying the same
+// centre +- edge/4 additions the reference performs (bitwise the same box).
+//
+// Neighbour search: uniform grid of edge 2 <h> (mean h) with a per-cell maximum of h; a particle
+// scans the cells C with dist(x, C) <= 2 max(h_i, hmax_C), which finds every j with
+// r <= 2 max(h_i, h_j) without making the cells as large as the largest h.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cmath>
+
+#include "pair_common.hpp"
+
+namespace sph {
+
+namespace {
+
+constexpr int VBLOCK = 256;
+constexpr int LEVELS = 21;            // 63-bit path keys
+constexpr uint32_t FLAG_D = 0x80000000u, FLAG_F = 0x40000000u, IDX_MASK = 0x3fffffffu;
+
+struct RootBox { double c[3]; double size; };
+
+__device__ __forceinline__ double wave_maxd(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sumd(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- h statistics -------------------------------------------------------------------------------
+__global__ __launch_bounds__(VBLOCK) void h_stats_partial(const double *__restrict__ h, int64_t n, double *__restrict__ part) {
+    __shared__ double sm[2][VBLOCK / WAVE];
+    double mx = 0.0, su = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VBLOCK) {
+        mx = fmax(mx, h[i]); su += h[i];
+    }
+    mx = wave_maxd(mx); su = wave_sumd(su);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mx; sm[1][threadIdx.x >> 6] = su; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < VBLOCK / WAVE; k++) { mx = fmax(mx, sm[0][k]); su += sm[1][k]; }
+        part[2 * blockIdx.x] = mx; part[2 * blockIdx.x + 1] = su;
+    }
+}
+
+__global__ void h_stats_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
+    double mx = 0.0, su = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) { mx = fmax(mx, part[2 * b]); su += part[2 * b + 1]; }
+    mx = wave_maxd(mx); su = wave_sumd(su);
+    if (threadIdx.x == 0) { out[0] = mx; out[1] = su; }
+}
+
+// ---- octree leaf boxes ----------------------------------------------------------------------------
+// path of the particle down the reference's octree: child index = (x > cx) | (y > cy) << 1 | (z > cz) << 2
+// ([V]:228-236), child centre = centre +- edge/4, child edge = edge/2 ([V]:212-222)
+__global__ __launch_bounds__(VBLOCK) void leaf_keys(RootBox rb, const double4 *__restrict__ prec, int64_t n,
+                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = prec[i];
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    uint64_t key = 0;
+    for (int l = 0; l < LEVELS; l++) {
+        const int bx = p.x > cx, by = p.y > cy, bz = p.z > cz;
+        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+        const double q = 0.25 * size;
+        cx = cx + (bx ? q : -q); cy = cy + (by ? q : -q); cz = cz + (bz ? q : -q);
+        size = size * 0.5;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ int common_levels(uint64_t a, uint64_t b) {
+    const uint64_t x = a ^ b;
+    if (x == 0) return LEVELS;
+    return (__clzll((long long)x) - 1) / 3;
+}
+
+// s = position in key order.  lrec[slot] = {leaf centre, reach = 2 h + edge/2}
+__global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec) {
+    const int64_t s = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t key = keys[s];
+    int cp = 0;
+    if (s > 0) cp = max(cp, common_levels(key, keys[s - 1]));
+    if (s + 1 < n) cp = max(cp, common_levels(key, keys[s + 1]));
+    // alone in the root box (n == 1): the root itself is the leaf; otherwise one level below the deepest
+    // node shared with another particle.  Keys identical over all 21 levels (closer than edge/2^21) would
+    // need deeper levels in the reference; the box is then taken at level 21.
+    const int level = n == 1 ? 0 : min(cp + 1, LEVELS);
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    for (int l = 1; l <= level; l++) {
+        const int ch = (int)((key >> (3 * (LEVELS - l))) & 7);
+        const double q = 0.25 * size;
+        cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+        size = size * 0.5;
+    }
+    const uint32_t slot = vals[s];
+    const double h = prec[slot].w;
+    lrec[slot] = make_double4(cx, cy, cz, 2.0 * h + size / 2.0);          // [V]:380,479
+}
+
+__global__ __launch_bounds__(VBLOCK) void cell_hmax_kernel(const int32_t *__restrict__ cell_start, int64_t ncells,
+                                                           const double4 *__restrict__ prec, double *__restrict__ hmax) {
+    const int64_t c = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
+    if (c >= ncells) return;
+    double m = 0.0;
+    for (int j = cell_start[c]; j < cell_start[c + 1]; j++) m = fmax(m, prec[j].w);
+    hmax[c] = m;
+}
+
+__device__ __forceinline__ bool reaches(const double4 &leaf, double x, double y, double z) {
+    return fabs(x - leaf.x) < leaf.w && fabs(y - leaf.y) < leaf.w && fabs(z - leaf.z) < leaf.w;
+}
+
+// distance^2 from coordinate p to the cell interval [lo, lo+e] along one axis
+__device__ __forceinline__ double axis_gap2(double p, double lo, double e) {
+    const double d = fmax(fmax(lo - p, p - (lo + e)), 0.0);
+    return d * d;
+}
+
+// ---- neighbour list ---------------------------------------------------------------------------------
+// entry = j | FLAG_D (j counts in i's density sum) | FLAG_F (pair {i,j} counts in the force sums)
+__global__ __launch_bounds__(VBLOCK) void nlist_v_kernel(GridDesc g, int R, double h_glob, const double4 *__restrict__ prec,
+                                                         const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
+                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
+                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
+                                                         int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
+                                                         int32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 6;
+    int cnt = 0;
+    if (i < n && orig[i] >= n_owned) ncount[i] = 0;
+    if (i < n && orig[i] < n_owned) {
+        const double4 pi = prec[i], li = lrec[i];
+        const int oi = orig[i];
+        const double p[3] = {pi.x, pi.y, pi.z};
+        int cc[3];
+        cell_coords(g, pi.x, pi.y, pi.z, cc);
+        const int s0 = g.s[0], s1 = g.s[1], s2 = g.s[2];
+        const int d0 = g.dim[s0], d1 = g.dim[s1], d2 = g.dim[s2];
+        const double e = 1.0 / g.inv_edge;
+        const double hi = pi.w;
+        const double rg = 2.0 * fmax(hi, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
+        const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
+        int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+        for (int c2 = max(cc[2] - R, 0); c2 <= min(cc[2] + R, d2 - 1); c2++) {
+            const double g2 = axis_gap2(p[s2], g.org[s2] + c2 * e, e);
+            if (g2 > rg2) continue;
+            for (int c1 = max(cc[1] - R, 0); c1 <= min(cc[1] + R, d1 - 1); c1++) {
+                const double g21 = g2 + axis_gap2(p[s1], g.org[s1] + c1 * e, e);
+                if (g21 > rg2) continue;
+                const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
+                for (int c0 = max(cc[0] - R, 0); c0 <= min(cc[0] + R, d0 - 1); c0++) {
+                    const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
+                    const double rc = 2.0 * fmax(hi, cell_hmax[row + c0]);
+                    if (gap > rc * rc * (1.0 + 1e-12)) continue;
+                    const int jb = cell_start[row + c0], je = cell_start[row + c0 + 1];
+                    for (int j = jb; j < je; j++) {
+                        const double4 pj = prec[j];
+                        const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                        const double r2 = dx * dx + dy * dy + dz * dz;
+                        const double hm = fmax(hi, pj.w);
+                        if (r2 <= 4.0 * hm * hm * (1.0 + 1e-12) && j != (int)i) {
+                            const double4 lj = lrec[j];
+                            const bool rij = reaches(lj, pi.x, pi.y, pi.z);       // i's walk reaches j's leaf
+                            const bool inD = rij && r2 <= ri2;                    // [V]:479 + kernel support of h_i
+                            const bool inF = oi > orig[j] ? rij : reaches(li, pj.x, pj.y, pj.z);   // [V]:383
+                            if (inD || inF) {
+                                if (cnt < cap) mine[(size_t)cnt * 64] = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u));
+                                cnt++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ncount[i] = cnt;
+    }
+    const int wm = wave_max_i32(cnt);
+    if (lane == 0 && (w << 6) < n) {
+        wave_max[w] = min(wm, cap);
+        if (wm > 0) atomicMax(&flags[1], wm);
+    }
+}
+
+// force gather record (FREC doubles): x y z m | vx vy vz rho/2 | P/(Omega rho^2)  c/2  alpha/2  h
+__device__ __forceinline__ void write_frec_v(double *__restrict__ frec, int64_t i, const double4 &pm, double vx, double vy,
+                                             double vz, double rho, double om, double P, double c, double alpha, double h) {
+    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
+    fr[0] = pm;
+    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
+    fr[2] = make_double4(P / (om * rho * rho), 0.5 * c, 0.5 * alpha, h);           // [V]:413
+}
+
+// ---- density + Omega + EOS ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const double4 *__restrict__ drec,
+                                                           const int32_t *__restrict__ nlist, int32_t cap,
+                                                           const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
+                                                           const double *__restrict__ w_tab, const double *__restrict__ dw_tab,
+                                                           int64_t n, const double *__restrict__ hh, const double *__restrict__ u,
+                                                           const double *__restrict__ alpha, const double *__restrict__ vx,
+                                                           const double *__restrict__ vy, const double *__restrict__ vz,
+                                                           double *__restrict__ rho, double *__restrict__ omega,
+                                                           double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec,
+                                                           const int32_t *__restrict__ orig, int32_t n_owned) {
+    extern __shared__ double lds[];
+    double *lw = lds, *ldw = lds + (pc.nq + 1);
+    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
+    __syncthreads();
+
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    if ((i & ~(int64_t)63) >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 6;
+    const bool live = i < n && orig[i] < n_owned;
+    const int self = i < n ? (int)i : (int)(n - 1);
+    const double4 pi = drec[self];
+    const double hi = hh[self];
+    const int cnt = live ? min(ncount[i], cap) : 0;
+    const int kmax = wave_max[w];
+    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
+
+    int e1 = 0 < cnt ? mine[0] : self;
+    int e2 = 1 < cnt ? mine[64] : self;
+    double4 p1 = drec[e1 & IDX_MASK];
+    double s1 = 0.0, s2 = 0.0;     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
+    for (int k = 0; k < kmax; k++) {
+        const double4 pj = p1;
+        const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
+        e1 = e2;
+        if (k + 2 < cnt) e2 = mine[(size_t)(k + 2) * 64];
+        if (k + 1 < cnt) p1 = drec[e1 & IDX_MASK];
+        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
+        double dr, rs;
+        fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
+        const double qi = dr * inv_h;
+        if (act && qi <= 2.0) {
+            double wl, dwl;
+            table_lerp2(lw, ldw, qi, inv_dq, pc.nq, wl, dwl);                            // [V]:486
+            s1 = fma(pj.w, wl, s1);                                                      // [V]:492
+            s2 = fma(pj.w, qi * dwl - 3.0 * wl, s2);                                     // [V]:487,493 (x -pi h^4)
+        }
+    }
+    if (!live) return;
+    s1 = fma(pi.w, lw[0], s1);                       // self: the walk reaches the body's own leaf, r = 0
+    s2 = fma(pi.w, -3.0 * lw[0], s2);
+    const double h3 = hi * hi * hi;
+    const double rhoi = s1 / (pc.kernel_pi * h3);                                        // [V]:139
+    const double om_acc = -s2 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));               // [V]:140,487
+    const double omi = 1.0 + (hi / (3.0 * rhoi)) * om_acc;                               // [V]:455
+    const double Pi = pc.gamma_m1 * u[i] * rhoi;                                         // [V]:509
+    const double ci = sqrt(pc.gamma * Pi / rhoi);                                        // [V]:510
+    rho[i] = rhoi; omega[i] = omi; P[i] = Pi; cs[i] = ci;
+    write_frec_v(frec, i, pi, vx[i], vy[i], vz[i], rhoi, omi, Pi, ci, alpha[i], hi);
+}
+
+__global__ __launch_bounds__(256) void eos_only_v_kernel(PairConst pc, int64_t n, const double4 *__restrict__ drec,
+                                                         const double *__restrict__ hh, const double *__restrict__ u,
+                                                         const double *__restrict__ alpha, const double *__restrict__ vx,
+                                                         const double *__restrict__ vy, const double *__restrict__ vz,
+                                                         const double *__restrict__ rho, const double *__restrict__ omega,
+                                                         double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double r = rho[i];
+    const double Pi = pc.gamma_m1 * u[i] * r;
+    const double ci = sqrt(pc.gamma * Pi / r);
+    P[i] = Pi; cs[i] = ci;
+    write_frec_v(frec, i, drec[i], vx[i], vy[i], vz[i], r, omega[i], Pi, ci, alpha[i], hh[i]);
+}
+
+// ---- forces, grad-h form ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const double *__restrict__ frec,
+                                                          const int32_t *__restrict__ nlist, int32_t cap,
+                                                          const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
+                                                          const double *__restrict__ dw_tab, const double *__restrict__ sink, int64_t n,
+                                                          double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
+                                                          double *__restrict__ du, double *__restrict__ dalpha,
+                                                          const int32_t *__restrict__ orig, int32_t n_owned) {
+    extern __shared__ double lds_dw[];
+    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) lds_dw[k] = dw_tab[k];
+    __syncthreads();
+
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    if ((i & ~(int64_t)63) >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 6;
+    const bool live = i < n && orig[i] < n_owned;
+    const int self = i < n ? (int)i : (int)(n - 1);
+    const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
+    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/(Om rho^2) c/2 alpha/2 h
+    const int cnt = live ? min(ncount[i], cap) : 0;
+    const int kmax = wave_max[w];
+    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const double hi = Cc.w;
+    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq, inv_pi = 1.0 / pc.kernel_pi;
+    const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
+
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
+    int e1 = 0 < cnt ? mine[0] : self;
+    int e2 = 1 < cnt ? mine[64] : self;
+    const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
+    double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
+    for (int k = 0; k < kmax; k++) {
+        const double4 Aj = A1, Bj = B1, Cj = C1;
+        const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
+        e1 = e2;
+        if (k + 2 < cnt) e2 = mine[(size_t)(k + 2) * 64];
+        if (k + 1 < cnt) {
+            fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
+            A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
+        }
+        const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
+        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+        double dr, rs;
+        fast_sqrt_rsqrt(r2, dr, rs);
+        if (act && r2 > 0.0) {
+            const double hj = Cj.w;
+            const double inv_hj = fast_rcp(hj);
+            const double qo = dr * inv_h, qn = dr * inv_hj;
+            const double ihj2 = inv_hj * inv_hj;
+            // dW(r, h_i) and dW(r, h_j), each normalised with its own h ([V]:395-396,140)
+            const double dWo = qo <= 2.0 ? table_lerp(lds_dw, qo, inv_dq, pc.nq) * inv_n4i : 0.0;
+            const double dWn = qn <= 2.0 ? table_lerp(lds_dw, qn, inv_dq, pc.nq) * (ihj2 * ihj2 * inv_pi) : 0.0;
+            const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;               // [V]:387
+            const double vr = v0 * n0 + v1 * n1 + v2 * n2;
+            const double vdotr = fmin(vr, 0.0);                                           // [V]:388-390
+            const double dWs = 0.5 * (dWo + dWn);
+            const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
+            const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
+            const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
+            const double cbar = Cc.y + Cj.y, abar = Cc.z + Cj.z;
+            const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
+            const double S = (Cc.x * dWo + Cj.x * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
+            const double mS = Aj.w * S;
+            s0 = fma(mS, n0, s0); s1 = fma(mS, n1, s1); s2 = fma(mS, n2, s2);             // [V]:416
+            const double mv = Aj.w * vdotgradW;
+            sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                        // [V]:419-421
+            sdal += mv;                                                                   // [V]:427
+        }
+    }
+    if (!live) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;     // zero_rates, then the gas side of sink_gravforces ([V]:691-)
+    for (int s = 0; s < pc.ns; s++) {
+        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
+        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        const double d3 = dr * dr * dr;
+        const double ms = sink[6 * MAX_SINKS + s];
+        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
+    }
+    ax[i] = a0 - s0; ay[i] = a1 - s1; az[i] = a2 - s2;
+    du[i] = sdu;
+    // [V]:346
+    dalpha[i] = fmax(sdal / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / hi);
+}
+
+// ---- calc_smoothing -------------------------------------------------------------------------------------
+// rho and Omega of ONE body with trial length hn on the tree of the last evaluation (leaf boxes and
+// reaches hold the OLD h of every particle), [V]:531-535 -> density_tree_search
+__device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec, const double4 *__restrict__ lrec,
+                            const int32_t *__restrict__ cell_start, const double *__restrict__ w_tab,
+                            const double *__restrict__ dw_tab, const PairConst &pc, const double4 &pi, double hn, double &rho,
+                            double &om) {
+    int cc[3];
+    cell_coords(g, pi.x, pi.y, pi.z, cc);
+    const int R = max((int)ceil(2.0 * hn * g.inv_edge), 1);
+    const int d0 = g.dim[g.s[0]], d1 = g.dim[g.s[1]], d2 = g.dim[g.s[2]];
+    double r0 = 0.0, oa = 0.0;
+    const double n3 = pc.kernel_pi * (hn * hn * hn), n4 = pc.kernel_pi * ((hn * hn) * (hn * hn));
+    for (int c2 = max(cc[2] - R, 0); c2 <= min(cc[2] + R, d2 - 1); c2++)
+        for (int c1 = max(cc[1] - R, 0); c1 <= min(cc[1] + R, d1 - 1); c1++) {
+            const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
+            const int jb = cell_start[row + max(cc[0] - R, 0)], je = cell_start[row + min(cc[0] + R, d0 - 1) + 1];
+            for (int j = jb; j < je; j++) {
+                const double4 lj = lrec[j];
+                if (!reaches(lj, pi.x, pi.y, pi.z)) continue;
+                const double4 pj = drec[j];
+                const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
+                const double dr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+                const double qi = dr / hn;
+                if (qi > 2.0) continue;
+                int k = min((int)(qi / pc.dq), pc.nq - 1);
+                const double a = (qi - k * pc.dq) / pc.dq;
+                const double Wj = ((1.0 - a) * w_tab[k] + a * w_tab[k + 1]) / n3;
+                const double dWj = ((1.0 - a) * dw_tab[k] + a * dw_tab[k + 1]) / n4;
+                const double W_h = -(dr * dWj - 3.0 * Wj) / hn;                           // [V]:487
+                r0 = r0 + pj.w * Wj;
+                oa = oa + pj.w * W_h;
+            }
+        }
+    rho = r0;
+    om = 1.0 + (hn / (3.0 * r0)) * oa;                                                     // [V]:535
+}
+
+__global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst pc, const double4 *__restrict__ drec,
+                                                          const double4 *__restrict__ lrec, const int32_t *__restrict__ cell_start,
+                                                          const double *__restrict__ w_tab, const double *__restrict__ dw_tab,
+                                                          int64_t n, const double *__restrict__ h_old, double *__restrict__ h_out,
+                                                          double *__restrict__ rho, double *__restrict__ omega,
+                                                          const int32_t *__restrict__ orig, int32_t n_owned) {
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double h0 = h_old[i];
+    if (orig[i] >= n_owned) { h_out[i] = h0; return; }
+    const double4 pi = drec[i];
+    double r = rho[i], om = omega[i];
+    double old_len = h0;
+    double t = pc.eta / h0;
+    double hn = h0 * (1.0 + ((pi.w * (t * t * t) / r) - 1.0) / (3.0 * om));              // [V]:527
+    if (hn < pc.h_max_length && hn > pc.h_min_length) {                                  // [V]:528
+        bool touched = false;
+        while (((hn - old_len) / old_len) > pc.h_tol && hn < pc.h_iter_cap) {            // [V]:529
+            old_len = hn;
+            density_one(g, drec, lrec, cell_start, w_tab, dw_tab, pc, pi, hn, r, om);    // [V]:531-535
+            touched = true;
+            t = pc.eta / hn;
+            hn = hn * (1.0 + ((pi.w * (t * t * t)) / r - 1.0) / (3.0 * om));             // [V]:538
+        }
+        if (touched) { rho[i] = r; omega[i] = om; }
+        h_out[i] = hn;
+    } else {
+        h_out[i] = old_len;                                                              // [V]:541
+    }
+}
+
+}  // namespace
+
+#define VH_CHECK(expr)                                                      \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) {                                             \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+            return SPH_ERR_HIP;                                             \
+        }                                                                   \
+    } while (0)
+
+hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes) {
+    size_t b = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (size_t)n, 0u, 63u, (hipStream_t) nullptr);
+    *bytes = b;
+    return e;
+}
+
+int varh_h_stats(sph_ctx *c) {
+    const int64_t n = c->n;
+    if (n == 0) { c->h_max_glob = c->h_mean = c->p.h; return SPH_OK; }
+    const int nb = (int)std::min<int64_t>((n + VBLOCK - 1) / VBLOCK, 512);
+    double *part = c->bbox_part;     // reuse the bbox partial buffer (>= 1024*6 doubles)
+    h_stats_partial<<<dim3(nb), dim3(VBLOCK), 0, c->stream>>>(c->f[SPH_F_H], n, part);
+    h_stats_final<<<dim3(1), dim3(64), 0, c->stream>>>(part, nb, part + 2048);
+    VH_CHECK(hipGetLastError());
+    VH_CHECK(hipMemcpyAsync(c->h_pinned + 28, part + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VH_CHECK(hipStreamSynchronize(c->stream));
+    c->h_max_glob = c->h_pinned[28];
+    c->h_mean = c->h_pinned[29] / (double)n;
+    if (!(c->h_max_glob > 0.0) || !std::isfinite(c->h_max_glob)) { c->err = "variable h: non-positive or non-finite smoothing length"; return SPH_ERR_ARG; }
+    return SPH_OK;
+}
+
+int varh_leaf_build(sph_ctx *c) {
+    const int64_t n = c->n;
+    if (n == 0) return SPH_OK;
+    // root box of the reference's create_tree, [V]:1007-1012, from the grid's bounding box (same min/max)
+    RootBox rb;
+    double size = 0.0;
+    for (int a = 0; a < 3; a++) {
+        rb.c[a] = (c->bbox[3 + a] + c->bbox[a]) / 2.0;
+        size = std::max(size, c->bbox[3 + a] - c->bbox[a]);
+    }
+    rb.size = size;
+    for (int a = 0; a < 3; a++) c->root_box[a] = rb.c[a];
+    c->root_box[3] = size;
+    const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
+    const double4 *prec = reinterpret_cast<const double4 *>(c->prec);
+    leaf_keys<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, prec, n, c->mkeys, c->mvals);
+    VH_CHECK(hipGetLastError());
+    size_t tmp = c->msort_tmp_bytes;
+    VH_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+    leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec));
+    VH_CHECK(hipGetLastError());
+    cell_hmax_kernel<<<dim3((unsigned)((c->grid.ncells + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
+        c->cell_start, c->grid.ncells, prec, c->cell_hmax);
+    VH_CHECK(hipGetLastError());
+    return SPH_OK;
+}
+
+int varh_nlist_build(sph_ctx *c) {
+    const int64_t n = c->n;
+    if (n == 0) return SPH_OK;
+    const int R = std::max(1, (int)std::ceil(2.0 * c->h_max_glob * c->grid.inv_edge * (1.0 + 1e-9)));
+    const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
+    for (int attempt = 0; attempt < 8; attempt++) {
+        VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
+        nlist_v_kernel<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
+            c->grid, R, c->h_max_glob, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
+            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->wave_max, c->d_flags);
+        VH_CHECK(hipGetLastError());
+        VH_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        VH_CHECK(hipStreamSynchronize(c->stream));
+        const int32_t mx = *reinterpret_cast<int32_t *>(c->h_pinned + 9);
+        c->nl_max = mx;
+        if (mx <= c->nl_cap) { c->nlist_builds++; return SPH_OK; }
+        ctx_free(c, c->nlist);
+        c->nl_cap = mx + mx / 8 + 8;
+        if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
+    }
+    c->err = "neighbour list did not converge";
+    return SPH_ERR_STATE;
+}
+
+hipError_t launch_density_v(sph_ctx *c, const PairConst &pc) {
+    if (c->n == 0) return hipSuccess;
+    const size_t lds = (size_t)(pc.nq + 1) * 2 * sizeof(double);
+    density_v_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
+        pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->dw_tab, c->n,
+        c->f[SPH_F_H], c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO],
+        c->f[SPH_F_OMEGA], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
+    return hipGetLastError();
+}
+
+hipError_t launch_eos_only_v(sph_ctx *c, const PairConst &pc) {
+    if (c->n == 0) return hipSuccess;
+    eos_only_v_kernel<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(
+        pc, c->n, reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_H], c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
+        c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->f[SPH_F_P], c->f[SPH_F_C], c->frec);
+    return hipGetLastError();
+}
+
+hipError_t launch_forces_v(sph_ctx *c, const PairConst &pc) {
+    if (c->n == 0) return hipSuccess;
+    const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    forces_v_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
+        pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY],
+        c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_h(sph_ctx *c, const PairConst &pc) {
+    if (c->n == 0) return hipSuccess;
+    update_h_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
+        c->grid, pc, reinterpret_cast<const double4 *>(c->drec), reinterpret_cast<const double4 *>(c->lrec), c->cell_start,
+        c->w_tab, c->dw_tab, c->n, c->f[SPH_F_H], c->h_new, c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->orig, (int32_t)c->n_owned);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) std::swap(c->f[SPH_F_H], c->h_new);
+    return e;
+}
+
+}  // namespace sph
