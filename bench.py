@@ -5,16 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one iteration of the reference's simulate() loop body (SUMMER_SPH.f90:889-916):
-2 density passes + 2 force passes + 2 half-kicks + 1 drift + the dt reduction, on a seeded
-synthetic Keplerian disc (summersph_amd/ic.py).  Inputs are resident in HBM before the timed
-region starts.  Rank 0 prints ONE JSON line.
+2 density passes + 2 force passes + 2 half-kicks + 1 drift + the dt reduction (variable-h: + the
+h update, Variable.f90:1152), on a seeded synthetic Keplerian disc (summersph_amd/ic.py).  Inputs
+are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
-Extra objects in that line:
-  roofline     dominant kernel (forces): ALGORITHMIC HBM bytes per launch (SURVEY.md 8(d):
-               80 B read + 40 B written per particle) / its mean launch duration, measured with
-               HIP events on the library's own stream during the timed steps; peak 8 TB/s.
-  cpu_baseline the CPU oracle (oracle/sph_oracle.c, OpenMP over all host cores) timed on a
-               bounded sample of the same workload on this box.
+Workloads
+  fixed (default, every N)   uniform disc, N x 1e6 gas particles + 1 sink, fixed h = 2.5: the [F] path
+                             (BASELINE configs[1] shape at the metric's N = 1e6); shards over GPUs as
+                             x-slabs with ghost exchange + migration over RCCL (summersph_amd/dist.py).
+  variable (N = 1)           BASELINE configs[2]: 1e6 particles, per-particle h, grad-h terms, the
+                             reference's leaf-box neighbour rule, h update every step.  At N = 1 the
+                             default run measures it too and reports it as "variable_h" next to the
+                             headline (the >= 1e7 target of BASELINE.md is quoted on this config).
+
+Extra objects in the JSON line
+  roofline     dominant kernel (forces): ALGORITHMIC HBM bytes per launch (80 B read
+               + 40 B written per particle) / its mean launch duration, measured with HIP events on
+               the library's own stream during the timed steps; peak 8 TB/s; traffic = PMC bytes of
+               the committed rocprofv3 passes (profiles/) when they were taken on this workload size.
+  cpu_baseline the CPU oracle (oracle/sph_oracle.c, OpenMP over the host cores) timed on a bounded
+               sample of the same workload on this box (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -30,6 +40,8 @@ sys.path.insert(0, ROOT)
 # algorithmic HBM bytes per particle per pass
 BYTES = {"density": 40 + 8, "forces": 80 + 40, "kick": 80 + 40, "drift": 48 + 24}
 BYTES_PER_STEP = 2 * (BYTES["density"] + BYTES["forces"]) + 2 * BYTES["kick"] + BYTES["drift"]   # 648
+BYTES_VAR = {"density": 48 + 16, "forces": 96 + 40}                                               # + h in, Omega out
+BYTES_PER_STEP_VAR = 2 * (BYTES_VAR["density"] + BYTES_VAR["forces"]) + 2 * BYTES["kick"] + BYTES["drift"] + 32   # ~744
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64
 # fp64 operations per pair visit as written in the kernels (div/sqrt counted as 1 each)
@@ -57,15 +69,46 @@ def cpu_baseline(n_total, nngb, seconds_target=15.0):
                       f"same surface density, OpenMP x{threads}, {t1 - t0:.1f} s"}
 
 
+def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags):
+    """one context on `device` with the workload uploaded from device memory"""
+    rows = ic.keplerian_disc_var(n, seed=303) if variable else ic.keplerian_disc(n, seed=202, nngb=nngb)
+    gas, sinks = ic.split_rows(rows)
+    ctx = capi.Context(device=device, variable=True) if variable else capi.Context(device=device, flags=flags)
+    dev = [torch.from_numpy(gas[k]).to(f"cuda:{device}") for k in "x y z vx vy vz u m alpha".split()]
+    torch.cuda.synchronize()
+    ctx.upload_dev(n, [t.data_ptr() for t in dev])               # inputs resident in HBM
+    if variable:
+        hdev = torch.from_numpy(gas["h"]).to(f"cuda:{device}")
+        torch.cuda.synchronize()
+        ctx.upload_field_dev("h", hdev.data_ptr(), n)
+    ctx.set_sinks(sinks)
+    return ctx
+
+
+def timed_run(ctx, torch, steps, warmup):
+    dt, t = ctx.run(warmup, 1e-2, 0.0)
+    ctx.timing(True); ctx.timing_reset()
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dt, t = ctx.run(steps, dt, t)
+    ctx.synchronize(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctx.timing(False)
+    return el, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", dest="n", type=int, default=1_000_000, help="gas particles per GPU")
-    ap.add_argument("--nngb", type=float, default=85.0, help="midplane neighbour target of the IC (mean is ~0.7x)")
+    ap.add_argument("--nngb", type=float, default=85.0, help="midplane neighbour target of the fixed-h IC (mean is ~0.6x)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-variable", action="store_true", help="skip the extra variable-h measurement at N = 1")
     ap.add_argument("--reuse-density", action="store_true", help="SPH_FLAG_REUSE_DENSITY (NOT the headline mode)")
+    ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
+                    help="headline workload; variable is single-GPU only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (host-staged messages)")
     args = ap.parse_args()
@@ -89,117 +132,114 @@ def main():
             dist.init_process_group(backend="gloo")
     red_dev = f"cuda:{local_rank}" if (world == 1 or args.backend == "nccl") else "cpu"
 
-    # ---- workload: seeded Keplerian disc, fixed h = 2.5 (the [F] path) ------------------------
-    # weak scaling: the disc holds n x world particles (same surface density, larger radius) and
-    # every rank owns one equal-count slab of it
-    rows = ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb)
-    gas, sinks = ic.split_rows(rows)
+    variable = args.mode == "variable"
+    if variable and world > 1:
+        raise SystemExit("the variable-h path is single-GPU this round (its octree leaf boxes need the global particle "
+                         "set); use --mode fixed for --gpus > 1")
     flags = capi.FLAG_REUSE_DENSITY if args.reuse_density else 0
+
+    # ---- headline workload -----------------------------------------------------------------------
+    sim = None
     if world == 1:
-        ctx = capi.Context(device=local_rank, flags=flags)
-        dev = [torch.from_numpy(gas[k]).to(f"cuda:{local_rank}") for k in "x y z vx vy vz u m alpha".split()]
-        torch.cuda.synchronize()
-        ctx.upload_dev(args.n, [t.data_ptr() for t in dev])       # inputs resident in HBM
-        ctx.set_sinks(sinks)
-        del dev
-        sim = None
+        ctx = make_single_ctx(capi, ic, torch, variable, args.n, args.nngb, local_rank, flags)
+        elapsed, dt = timed_run(ctx, torch, args.steps, args.warmup)
+        n_max = [args.n, 0]
     else:
+        # weak scaling: the disc holds n x world particles (same surface density, larger radius); every rank
+        # owns one equal-count x-slab of it
         from summersph_amd.dist import DistSim, HipBackend, slab_bounds
+        rows = ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb)
+        gas, sinks = ic.split_rows(rows)
         bounds = slab_bounds(gas["x"], world)
-        owner = np.searchsorted(bounds, gas["x"], side="right")
-        sel = owner == rank
+        sel = np.searchsorted(bounds, gas["x"], side="right") == rank
         mine = {k: v[sel] for k, v in gas.items()}
         mine["gid"] = np.nonzero(sel)[0]
+        del rows, gas
         be = HipBackend(local_rank, flags=flags)
         # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
         sim = DistSim(be, mine, sinks, bounds, group=None, comm_device=None if args.backend == "nccl" else "cpu")
         ctx = be.ctx
-    del rows, gas
 
-    def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def barrier():
+            ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
 
-    def run(k, dt, t):
-        if sim is None:
-            return ctx.run(k, dt, t)
-        for _ in range(k):
-            dt = sim.step(dt)
-        return dt, sim.t
-
-    dt, t = 1e-2, 0.0
-    dt, t = run(args.warmup, dt, t)
-    ctx.timing(True); ctx.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    dt, t = run(args.steps, dt, t)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.timing(False)
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    n_loc = torch.tensor([float(sim.n_owned if sim is not None else args.n), float(sim.stats["ghosts"] if sim is not None else 0)],
-                         dtype=torch.float64, device=red_dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        n_max = n_loc.clone()
-        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
-    else:
-        n_max = n_loc
-    elapsed = float(el.item())
+        dt = sim.run(args.warmup, 1e-2)
+        ctx.timing(True); ctx.timing_reset()
+        barrier()
+        t0 = time.perf_counter()
+        dt = sim.run(args.steps, dt)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.timing(False)
+        red = torch.tensor([elapsed, float(sim.n_owned), float(sim.stats["ghosts"])], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed, n_max = float(red[0]), [int(red[1]), int(red[2])]
 
     if rank == 0:
         st = ctx.stats()
         kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
         f_ms, f_cnt = kt["forces"]
         f_avg_s = f_ms / max(f_cnt, 1) * 1e-3
-        n_slots = st.n                                      # owned + ghosts held by rank 0's context
+        bytes_forces = (BYTES_VAR if variable else BYTES)["forces"]
+        alg_bytes = bytes_forces * args.n
+        achieved = alg_bytes / f_avg_s / 1e9
+        value = args.n * world * args.steps / elapsed
+        bps = BYTES_PER_STEP_VAR if variable else BYTES_PER_STEP
+        pair_visits = 2 * 2 * st.nlist_mean * args.n * args.steps / elapsed
+        flops = (FLOPS_DENSITY_PAIR + FLOPS_FORCE_PAIR) * 2 * st.nlist_mean * args.n * args.steps / elapsed / 1e12
         # HBM traffic of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 on
-        # itself); only quoted when it was measured on this very workload size
+        # itself); only quoted when it was measured on this very workload
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_forces_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and world == 1 and not variable:
             rec = json.load(open(tf))
-            if rec.get("workload_particles") == args.n and world == 1:
+            if rec.get("workload_particles") == args.n:
                 traffic = rec["traffic_bytes_per_launch"]
-        alg_bytes = BYTES["forces"] * args.n
-        achieved = alg_bytes / f_avg_s / 1e9
-        pairs_per_step = 2 * 2 * st.nlist_mean * args.n     # density + force visits, 2 evaluations
-        value = args.n * world * args.steps / elapsed
-        flops = (FLOPS_DENSITY_PAIR + FLOPS_FORCE_PAIR) * 2 * st.nlist_mean * args.n * args.steps / elapsed / 1e12
+        wl = (f"uniform Keplerian disc, {args.n} gas particles + 1 sink per GPU, "
+              + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
+                 if variable else "fixed h=2.5 ([F] path, BASELINE configs[1] shape at the metric's N=1e6), ")
+              + f"mean {st.nlist_mean:.1f} list entries per particle, 2 density + 2 force passes per step")
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"uniform Keplerian disc, {args.n} gas particles + 1 sink per GPU, fixed h=2.5 "
-                                   f"([F] path, BASELINE configs[1] shape at the metric's N=1e6), "
-                                   f"mean {st.nlist_mean:.1f} neighbours inside 2h, 2 density + 2 force passes per step",
-                       "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean,
-                       "max_neighbours": st.nlist_max, "grid": list(st.grid_dim),
-                       "reuse_density": bool(args.reuse_density),
+            "config": {"workload": wl, "mode": args.mode, "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean,
+                       "max_neighbours": st.nlist_max, "grid": list(st.grid_dim), "reuse_density": bool(args.reuse_density),
                        "parallelism": "1 GPU" if world == 1 else
-                                      f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed nccl)",
-                       "max_owned_per_gpu": int(n_max[0].item()), "max_ghosts_per_gpu": int(n_max[1].item()),
-                       "rank0_slots": int(n_slots)},
-            "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                      f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed {args.backend})",
+                       "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
+            "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else "forces_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
-                         "note": "compulsory HBM traffic is tiny for this path; the pair loop is fp64-VALU / "
-                                 "gather bound, see valu_fp64"},
+                         "note": "compulsory HBM traffic is tiny for this path; the pair loop is bound by the L1/TA gather "
+                                 "path and fp64 VALU (profiles/), see valu_fp64"},
             "valu_fp64": {"achieved_tflops_est": flops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": flops / FP64_PEAK_TFLOPS,
-                          "pair_visits_per_s": pairs_per_step * args.steps / elapsed},
-            "hbm_step": {"algorithmic_bytes_per_particle_step": BYTES_PER_STEP,
-                         "achieved_GBs": BYTES_PER_STEP * value / world / 1e9},
+                          "pair_visits_per_s": pair_visits},
+            "hbm_step": {"algorithmic_bytes_per_particle_step": bps, "achieved_GBs": bps * value / world / 1e9},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
             "final_dt": dt, "device_bytes": st.device_bytes,
         }
+        ctx.close()
+        if world == 1 and not variable and not args.no_variable:
+            # BASELINE configs[2] on the same GPU, same step count
+            vctx = make_single_ctx(capi, ic, torch, True, args.n, args.nngb, local_rank, 0)
+            vel, vdt = timed_run(vctx, torch, args.steps, args.warmup)
+            vst = vctx.stats()
+            vkt = {k: vctx.timing_get(k) for k in capi.KERNELS}
+            out["variable_h"] = {
+                "workload": f"BASELINE configs[2]: uniform Keplerian disc, {args.n} particles, variable h "
+                            f"(h 2.5..8, eta 1.2), grad-h, leaf-box neighbour rule, h update every step",
+                "value": args.n * args.steps / vel, "unit": "particle-steps/s", "ms_per_step": vel / args.steps * 1e3,
+                "mean_list_entries": vst.nlist_mean, "max_list_entries": vst.nlist_max, "grid": list(vst.grid_dim),
+                "kernel_ms_per_step": {k: v[0] / args.steps for k, v in vkt.items()}, "final_dt": vdt,
+                "target_BASELINE_md": 1.0e7}
+            vctx.close()
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n, args.nngb)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    else:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
