@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variable", action="store_true", help="skip the extra variable-h measurement at N = 1")
     ap.add_argument("--reuse-density", action="store_true", help="SPH_FLAG_REUSE_DENSITY (NOT the headline mode)")
+    ap.add_argument("--no-tiles", action="store_true", help="SPH_FLAG_NO_LDS_TILES: per-lane-gather list build (A/B)")
+    ap.add_argument("--tile-eval", action="store_true", help="SPH_FLAG_LDS_TILE_EVAL: LDS-staged density/forces (A/B)")
     ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
                     help="headline workload; variable is single-GPU only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -136,7 +138,8 @@ def main():
     if variable and world > 1:
         raise SystemExit("the variable-h path is single-GPU this round (its octree leaf boxes need the global particle "
                          "set); use --mode fixed for --gpus > 1")
-    flags = capi.FLAG_REUSE_DENSITY if args.reuse_density else 0
+    flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
+        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0)
 
     # ---- headline workload -----------------------------------------------------------------------
     sim = None

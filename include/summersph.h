@@ -74,6 +74,11 @@ typedef struct sph_params {
                                    neighbour rule of the reference's variable-h variant [V]:
                                    kernel normalised with h_i and REAL(4) pi, nq = 2500, Omega,
                                    h update after every step.  Upload h with sph_upload_field. */
+#define SPH_FLAG_NO_LDS_TILES 4  /* fixed-h path: build the neighbour list with per-lane gathers (pairs.hip)
+                                   instead of LDS-staged tiles (tiled.hip); A/B measurements        */
+#define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
+                                   results up to summation order; measured SLOWER than the default
+                                   direct gathers on MI355X, kept for tuning  */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
                                     change since the last one (bitwise the same rho); OFF by
                                     default: the reference recomputes it, [F]:896,908 */

@@ -18,6 +18,8 @@ FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "
 KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h"]
 FLAG_REUSE_DENSITY = 1
 FLAG_VARIABLE_H = 2
+FLAG_NO_LDS_TILES = 4
+FLAG_LDS_TILE_EVAL = 8
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [

@@ -147,7 +147,7 @@ int do_density(sph_ctx *c) {
             { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
             { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
         } else {
-            Timed t(c, SPH_K_NLIST); API_TRY(nlist_build(c));
+            Timed t(c, SPH_K_NLIST); API_TRY(c->tiled ? nlist_build_tiled(c) : nlist_build(c));
         }
         c->grid_valid = true;
     }
@@ -156,7 +156,7 @@ int do_density(sph_ctx *c) {
     if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
         API_HIP(c->variable ? launch_eos_only_v(c, pc) : launch_eos_only(c, pc));
     } else {
-        API_HIP(c->variable ? launch_density_v(c, pc) : launch_density(c, pc));
+        API_HIP(c->variable ? launch_density_v(c, pc) : (c->tiled_eval ? launch_density_tiled(c, pc) : launch_density(c, pc)));
         c->density_passes++;
     }
     c->rho_valid = true; c->eos_valid = true;
@@ -167,7 +167,7 @@ int do_forces(sph_ctx *c) {
     if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces: call sph_density first"; return SPH_ERR_STATE; }
     const PairConst pc = make_pair_const(c);
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : launch_forces(c, pc)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc) : launch_forces(c, pc))); }
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -330,6 +330,9 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if (!c) return SPH_ERR_NOMEM;
     c->p = *p;
     c->variable = (p->flags & SPH_FLAG_VARIABLE_H) != 0;
+    c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
+    c->tiled_eval = c->tiled && (p->flags & SPH_FLAG_LDS_TILE_EVAL) != 0;
+    c->packed_list = c->tiled;
     c->device = device;
     DeviceGuard g(device);
     int st = SPH_OK;
@@ -341,6 +344,8 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->w_pair, (size_t)2 * p->nq, "W pair table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->dw_pair, (size_t)2 * p->nq, "dW pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->sink, (size_t)10 * MAX_SINKS, "sinks")) != SPH_OK) return fail(st);
     c->sink_blocks = 512;
     if ((st = ctx_alloc(c, &c->sink_part, (size_t)c->sink_blocks * MAX_SINKS * 3, "sink partials")) != SPH_OK) return fail(st);
@@ -349,6 +354,10 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->d_dt, 4, "dt")) != SPH_OK) return fail(st);
     std::vector<double> w, dw;
     host_tables(p->nq, w, dw);
+    std::vector<double> wp((size_t)2 * p->nq), dwp((size_t)2 * p->nq);
+    for (int k = 0; k < p->nq; k++) { wp[2 * k] = w[k]; wp[2 * k + 1] = w[k + 1]; dwp[2 * k] = dw[k]; dwp[2 * k + 1] = dw[k + 1]; }
+    if (hipMemcpy(c->w_pair, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->dw_pair, dwp.data(), dwp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SPH_ERR_HIP);
     if (hipMemcpy(c->w_tab, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->dw_tab, dw.data(), dw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->sink, 0, sizeof(double) * 10 * MAX_SINKS) != hipSuccess ||
@@ -365,7 +374,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     resolve_timing(c);
     free_particle_arrays(c);
     ctx_free(c, c->cell_start); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
-    ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
+    ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);

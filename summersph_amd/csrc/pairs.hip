@@ -105,7 +105,18 @@ __device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i,
     fr[2] = make_double4(P / (rho * rho), 0.5 * c, 0.5 * alpha, 0.0);       // [F]:381: P/(rho*rho)
 }
 
-template <int BLOCK>
+// entry k of a lane's list: wave-strided dwords (PACKED = false, nlist_kernel) or the 4-packed layout of
+// the tiled list build (PACKED = true: component k%4 of the int4 at row k/4), both read in lockstep
+template <bool PACKED>
+__device__ __forceinline__ const int32_t *list_base(const int32_t *nlist, int64_t w, int32_t cap, int lane) {
+    return PACKED ? nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4 : nlist + ((size_t)w * cap) * 64 + lane;
+}
+template <bool PACKED>
+__device__ __forceinline__ size_t list_off(int k) {
+    return PACKED ? (size_t)(k >> 2) * 256 + (k & 3) : (size_t)k * 64;
+}
+
+template <int BLOCK, bool PACKED>
 __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const double4 *__restrict__ drec,
                                                         const int32_t *__restrict__ nlist, int32_t cap,
                                                         const int32_t *__restrict__ ncount,
@@ -130,21 +141,21 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     const double4 pi = drec[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const int32_t *mine = list_base<PACKED>(nlist, w, cap, lane);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
     // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
     // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
     // Lanes past their own count re-read their own record (a valid address) and are masked out.
-    int j1 = 0 < cnt ? mine[0] : self;
-    int j2 = 1 < cnt ? mine[64] : self;
+    int j1 = 0 < cnt ? mine[list_off<PACKED>(0)] : self;
+    int j2 = 1 < cnt ? mine[list_off<PACKED>(1)] : self;
     double4 p1 = drec[j1];
     double acc = 0.0;   // sum of m_j * w(q_ij), normalised once at the end
     for (int k = 0; k < kmax; k++) {
         const double4 pj = p1;
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = mine[(size_t)(k + 2) * 64];
+        if (k + 2 < cnt) j2 = mine[list_off<PACKED>(k + 2)];
         if (k + 1 < cnt) p1 = drec[j1];          // idle lanes issue no gather
         const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
         double dr, rs;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256) void eos_only_kernel(PairConst pc, int64_t n, 
 // ------------------------------------------------------------------------------------------
 // forces: sink gravity on the gas, SPH pressure + artificial viscosity, du/dt, dalpha/dt
 // ------------------------------------------------------------------------------------------
-template <int BLOCK>
+template <int BLOCK, bool PACKED>
 __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const double *__restrict__ frec,
                                                        const int32_t *__restrict__ nlist, int32_t cap,
                                                        const int32_t *__restrict__ ncount,
@@ -209,21 +220,21 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/rho^2 c/2 alpha/2 -
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const int32_t *mine = list_base<PACKED>(nlist, w, cap, lane);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
     // SPH sums, un-normalised: every term is linear in dW, so 1/(pi h^4) ([F]:126) is applied once at the end
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
 
-    int j1 = 0 < cnt ? mine[0] : self;
-    int j2 = 1 < cnt ? mine[64] : self;
+    int j1 = 0 < cnt ? mine[list_off<PACKED>(0)] : self;
+    int j2 = 1 < cnt ? mine[list_off<PACKED>(1)] : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
         const double4 Aj = A1, Bj = B1, Cj = C1;
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = mine[(size_t)(k + 2) * 64];
+        if (k + 2 < cnt) j2 = mine[list_off<PACKED>(k + 2)];
         if (k + 1 < cnt) {                       // idle lanes issue no gather
             fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
@@ -399,7 +410,8 @@ int nlist_build(sph_ctx *c) {
 hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
-    density_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
+    auto k = c->packed_list ? density_kernel<PAIR_BLOCK, true> : density_kernel<PAIR_BLOCK, false>;
+    k<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->n,
         c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P],
         c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
@@ -417,7 +429,8 @@ hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc) {
 hipError_t launch_forces(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
-    forces_kernel<PAIR_BLOCK><<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
+    auto k = c->packed_list ? forces_kernel<PAIR_BLOCK, true> : forces_kernel<PAIR_BLOCK, false>;
+    k<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
     return hipGetLastError();

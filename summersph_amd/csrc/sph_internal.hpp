@@ -75,6 +75,9 @@ struct sph_ctx {
 
     // variable-h path ("SUMMER_SPH - Variable.f90"): extra gather records and the octree leaf boxes
     bool variable = false;
+    bool tiled = true;               // fixed-h: LDS-staged neighbour-list build (tiled.hip) unless SPH_FLAG_NO_LDS_TILES
+    bool tiled_eval = false;         // fixed-h: LDS-staged density/forces too (SPH_FLAG_LDS_TILE_EVAL; slower)
+    bool packed_list = true;         // list layout: 4-packed (tiled build) or wave-strided dwords (nlist_kernel)
     double *prec = nullptr;          // 4 doubles: x y z h        (neighbour-list build)
     double *lrec = nullptr;          // 4 doubles: leaf centre x y z, reach = 2h + leaf_edge/2 (<0: unresolved)
     uint64_t *mkeys = nullptr, *mkeys_alt = nullptr;   // octree path keys (3 bits per level, 21 levels)
@@ -103,6 +106,7 @@ struct sph_ctx {
 
     // kernel tables on the device
     double *w_tab = nullptr, *dw_tab = nullptr;
+    double *w_pair = nullptr, *dw_pair = nullptr;    // pair-packed copies: entry k = {t[k], t[k+1]} (16-B aligned)
 
     // sinks on the device: 10 arrays of MAX_SINKS doubles: x y z vx vy vz m ax ay az
     int32_t ns = 0;
@@ -163,6 +167,10 @@ hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_
 hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out);
 hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals);
 hipError_t launch_dt_partial_only(sph_ctx *c);
+// LDS-tiled fixed-h kernels (tiled.hip; default)
+int nlist_build_tiled(sph_ctx *c);
+hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);
+hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
 // variable-h path (varh.hip)
 hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)
