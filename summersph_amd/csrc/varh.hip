@@ -144,44 +144,86 @@ __device__ __forceinline__ double axis_gap2(double p, double lo, double e) {
 
 // ---- neighbour list ---------------------------------------------------------------------------------
 // entry = j | FLAG_D (j counts in i's density sum) | FLAG_F (pair {i,j} counts in the force sums)
-__global__ __launch_bounds__(VBLOCK) void nlist_v_kernel(GridDesc g, int R, double h_glob, const double4 *__restrict__ prec,
-                                                         const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
-                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
-                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
-                                                         int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
-                                                         int32_t *__restrict__ flags) {
+// layout: 4-packed, wave-strided (entry k of lane l in wave w = component k%4 of the int4 at
+// nlist4[(w*cap/4 + k/4)*64 + l]); the evaluation kernels read it in lockstep.
+__device__ __forceinline__ size_t voff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
+
+// Built from LDS-staged tiles.  For every offset o2 along the slowest grid axis
+// the candidates of a 256-particle workgroup lie in ONE contiguous interval of the sorted order (all
+// columns within R of the workgroup's columns); it is staged chunk-wise with coalesced loads and each lane
+// scans its own cells out of LDS instead of gathering every candidate through the TA.
+constexpr int T_NV = 1024;
+
+__global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, double h_glob, const double4 *__restrict__ prec,
+                                                        const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
+                                                        const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
+                                                        int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
+                                                        int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
+                                                        int32_t *__restrict__ flags) {
+    __shared__ double4 tile[T_NV];
+    __shared__ int s_lo[VBLOCK / WAVE], s_hi[VBLOCK / WAVE];
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
+    const bool live = i < n && orig[i] < n_owned;
+    const int64_t self = i < n ? i : n - 1;
+    const double4 pi = prec[self], li = lrec[self];
+    const int oi = orig[self];
+    const double p[3] = {pi.x, pi.y, pi.z};
+    int cc[3];
+    cell_coords(g, pi.x, pi.y, pi.z, cc);
+    const int s0 = g.s[0], s1 = g.s[1], s2 = g.s[2];
+    const int d0 = g.dim[s0], d1 = g.dim[s1], d2 = g.dim[s2];
+    const double e = 1.0 / g.inv_edge;
+    const double hi = pi.w;
+    const double rg = 2.0 * fmax(hi, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
+    const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
+    const int c1lo = max(cc[1] - R, 0), c1hi = min(cc[1] + R, d1 - 1);
+    const int c0lo = max(cc[0] - R, 0), c0hi = min(cc[0] + R, d0 - 1);
+    int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
+    int4 buf = make_int4(0, 0, 0, 0);
     int cnt = 0;
-    if (i < n && orig[i] >= n_owned) ncount[i] = 0;
-    if (i < n && orig[i] < n_owned) {
-        const double4 pi = prec[i], li = lrec[i];
-        const int oi = orig[i];
-        const double p[3] = {pi.x, pi.y, pi.z};
-        int cc[3];
-        cell_coords(g, pi.x, pi.y, pi.z, cc);
-        const int s0 = g.s[0], s1 = g.s[1], s2 = g.s[2];
-        const int d0 = g.dim[s0], d1 = g.dim[s1], d2 = g.dim[s2];
-        const double e = 1.0 / g.inv_edge;
-        const double hi = pi.w;
-        const double rg = 2.0 * fmax(hi, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
-        const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
-        int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
-        for (int c2 = max(cc[2] - R, 0); c2 <= min(cc[2] + R, d2 - 1); c2++) {
-            const double g2 = axis_gap2(p[s2], g.org[s2] + c2 * e, e);
-            if (g2 > rg2) continue;
-            for (int c1 = max(cc[1] - R, 0); c1 <= min(cc[1] + R, d1 - 1); c1++) {
+
+    for (int o2 = -R; o2 <= R; o2++) {
+        const int c2 = cc[2] + o2;
+        const bool in2 = live && c2 >= 0 && c2 < d2;
+        const double g2 = in2 ? axis_gap2(p[s2], g.org[s2] + c2 * e, e) : 0.0;
+        const bool use2 = in2 && g2 <= rg2;
+        // the workgroup's interval for this offset
+        int mn = 0x7fffffff, mx = 0;
+        if (use2) {
+            mn = cell_start[((int64_t)c2 * d1 + c1lo) * d0 + c0lo];
+            mx = cell_start[((int64_t)c2 * d1 + c1hi) * d0 + c0hi + 1];
+            if (mx <= mn) { mn = 0x7fffffff; mx = 0; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+        __syncthreads();
+        if (lane == 0) { s_lo[threadIdx.x >> 6] = mn; s_hi[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        const int lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        const int hiv = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        for (int cb = lo; cb < hiv; cb += T_NV) {
+            const int ce = min(cb + T_NV, hiv);
+            __syncthreads();
+            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) tile[t] = prec[cb + t];
+            __syncthreads();
+            if (!use2) continue;
+            // per-lane walk over this lane's own columns and cells (lanes of different columns advance in
+            // parallel; a wave-uniform walk with scalar table loads was measured 2x slower because waves that
+            // straddle two columns then serialise)
+            for (int c1 = c1lo; c1 <= c1hi; c1++) {
                 const double g21 = g2 + axis_gap2(p[s1], g.org[s1] + c1 * e, e);
                 if (g21 > rg2) continue;
                 const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
-                for (int c0 = max(cc[0] - R, 0); c0 <= min(cc[0] + R, d0 - 1); c0++) {
+                if (cell_start[row + c0hi + 1] <= cb || cell_start[row + c0lo] >= ce) continue;   // row not in this chunk
+                for (int c0 = c0lo; c0 <= c0hi; c0++) {
+                    const int jb = max(cell_start[row + c0], cb), je = min(cell_start[row + c0 + 1], ce);
+                    if (jb >= je) continue;
                     const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
                     const double rc = 2.0 * fmax(hi, cell_hmax[row + c0]);
                     if (gap > rc * rc * (1.0 + 1e-12)) continue;
-                    const int jb = cell_start[row + c0], je = cell_start[row + c0 + 1];
                     for (int j = jb; j < je; j++) {
-                        const double4 pj = prec[j];
+                        const double4 pj = tile[j - cb];
                         const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                         const double r2 = dx * dx + dy * dy + dz * dz;
                         const double hm = fmax(hi, pj.w);
@@ -191,7 +233,10 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_kernel(GridDesc g, int R, doub
                             const bool inD = rij && r2 <= ri2;                    // [V]:479 + kernel support of h_i
                             const bool inF = oi > orig[j] ? rij : reaches(li, pj.x, pj.y, pj.z);   // [V]:383
                             if (inD || inF) {
-                                if (cnt < cap) mine[(size_t)cnt * 64] = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u));
+                                const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u));
+                                const int q4 = cnt & 3;
+                                if (q4 == 0) buf.x = ent; else if (q4 == 1) buf.y = ent; else if (q4 == 2) buf.z = ent; else buf.w = ent;
+                                if (q4 == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
                                 cnt++;
                             }
                         }
@@ -199,9 +244,10 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_kernel(GridDesc g, int R, doub
                 }
             }
         }
-        ncount[i] = cnt;
     }
-    const int wm = wave_max_i32(cnt);
+    if ((cnt & 3) != 0 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
+    if (i < n) ncount[i] = live ? cnt : 0;
+    const int wm = wave_max_i32(live ? cnt : 0);
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
         if (wm > 0) atomicMax(&flags[1], wm);
@@ -243,18 +289,18 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     const double hi = hh[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
 
-    int e1 = 0 < cnt ? mine[0] : self;
-    int e2 = 1 < cnt ? mine[64] : self;
+    int e1 = 0 < cnt ? mine[voff(0)] : self;
+    int e2 = 1 < cnt ? mine[voff(1)] : self;
     double4 p1 = drec[e1 & IDX_MASK];
     double s1 = 0.0, s2 = 0.0;     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
     for (int k = 0; k < kmax; k++) {
         const double4 pj = p1;
         const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
         e1 = e2;
-        if (k + 2 < cnt) e2 = mine[(size_t)(k + 2) * 64];
+        if (k + 2 < cnt) e2 = mine[voff(k + 2)];
         if (k + 1 < cnt) p1 = drec[e1 & IDX_MASK];
         const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
         double dr, rs;
@@ -317,21 +363,21 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/(Om rho^2) c/2 alpha/2 h
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = nlist + ((size_t)w * cap) * 64 + lane;
+    const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
     const double hi = Cc.w;
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq, inv_pi = 1.0 / pc.kernel_pi;
     const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
 
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-    int e1 = 0 < cnt ? mine[0] : self;
-    int e2 = 1 < cnt ? mine[64] : self;
+    int e1 = 0 < cnt ? mine[voff(0)] : self;
+    int e2 = 1 < cnt ? mine[voff(1)] : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
         const double4 Aj = A1, Bj = B1, Cj = C1;
         const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
         e1 = e2;
-        if (k + 2 < cnt) e2 = mine[(size_t)(k + 2) * 64];
+        if (k + 2 < cnt) e2 = mine[voff(k + 2)];
         if (k + 1 < cnt) {
             fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
@@ -398,11 +444,13 @@ __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec,
             const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
             const int jb = cell_start[row + max(cc[0] - R, 0)], je = cell_start[row + min(cc[0] + R, d0 - 1) + 1];
             for (int j = jb; j < je; j++) {
-                const double4 lj = lrec[j];
-                if (!reaches(lj, pi.x, pi.y, pi.z)) continue;
                 const double4 pj = drec[j];
                 const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
-                const double dr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+                const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+                if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) continue;       // cheap pre-test; the exact one follows
+                const double4 lj = lrec[j];
+                if (!reaches(lj, pi.x, pi.y, pi.z)) continue;
+                const double dr = sqrt(r2);
                 const double qi = dr / hn;
                 if (qi > 2.0) continue;
                 int k = min((int)(qi / pc.dq), pc.nq - 1);
@@ -518,7 +566,7 @@ int varh_nlist_build(sph_ctx *c) {
     const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
     for (int attempt = 0; attempt < 8; attempt++) {
         VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
-        nlist_v_kernel<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
+        nlist_v_tiled<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
             c->grid, R, c->h_max_glob, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
             c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->wave_max, c->d_flags);
         VH_CHECK(hipGetLastError());
@@ -528,7 +576,7 @@ int varh_nlist_build(sph_ctx *c) {
         c->nl_max = mx;
         if (mx <= c->nl_cap) { c->nlist_builds++; return SPH_OK; }
         ctx_free(c, c->nlist);
-        c->nl_cap = mx + mx / 8 + 8;
+        c->nl_cap = ((mx + mx / 8 + 8) + 3) & ~3;
         if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
     }
     c->err = "neighbour list did not converge";
