@@ -67,6 +67,8 @@ typedef struct sph_params {
     double h_max_length; /* max_length ([V]:528)                                              */
     double h_min_length; /* (double)0.01f ([V]:528)                                           */
     double h_iter_cap;   /* 10.0 ([V]:529)                                                    */
+    /* Barnes-Hut gas self-gravity (flags & SPH_FLAG_SELF_GRAVITY)                              */
+    double theta;        /* 0.5: opening angle, hard coded at the call site [F]:825 / [V]:1029 */
 } sph_params;
 
 /* flags */
@@ -74,6 +76,8 @@ typedef struct sph_params {
                                    neighbour rule of the reference's variable-h variant [V]:
                                    kernel normalised with h_i and REAL(4) pi, nq = 2500, Omega,
                                    h update after every step.  Upload h with sph_upload_field. */
+#define SPH_FLAG_SELF_GRAVITY 16 /* find_forces WITH the Barnes-Hut gas self-gravity term (particle_gravforces,
+                                   [F]:249-290, 825): sph_forces then equals find_forces as it is.  Single GPU. */
 #define SPH_FLAG_NO_LDS_TILES 4  /* fixed-h path: build the neighbour list with per-lane gathers (pairs.hip)
                                    instead of LDS-staged tiles (tiled.hip); A/B measurements        */
 #define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
@@ -102,6 +106,7 @@ enum sph_kernel_id {
     SPH_K_KICK, SPH_K_DRIFT, SPH_K_DT,
     SPH_K_LEAF,        /* variable-h: octree leaf boxes (Morton keys, sort, depth)             */
     SPH_K_UPDATE_H,    /* variable-h: calc_smoothing                                          */
+    SPH_K_GRAVITY,     /* self-gravity: octree keys, radix tree, node sums, tree walk          */
     SPH_K_COUNT
 };
 
@@ -150,8 +155,8 @@ int sph_upload_field_dev(sph_ctx *ctx, int field, const double *d_vals, int64_t 
 /* ---- the hot path ------------------------------------------------------------------- */
 /* create_tree + get_density + get_pressure_and_sound_speed   ([F]:894-897, 398-468)      */
 int sph_density(sph_ctx *ctx);
-/* find_forces minus the Barnes-Hut gas self-gravity term: zero_rates, sink_gravforces,
- * get_SPH   ([F]:818-829, 559-591, 295-395)                                              */
+/* find_forces ([F]:818-829): zero_rates, [particle_gravforces when SPH_FLAG_SELF_GRAVITY],
+ * sink_gravforces, get_SPH   ([F]:249-290, 559-591, 295-395)                             */
 int sph_forces(sph_ctx *ctx);
 /* kick ([F]:742-759) and drift ([F]:762-776), gas and sinks                              */
 int sph_kick(sph_ctx *ctx, double dt);

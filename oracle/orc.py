@@ -18,7 +18,7 @@ _D = C.POINTER(C.c_double)
 
 def build() -> str:
     path = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sph_oracle.c", "sph_oracle_v.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("sph_oracle.c", "sph_oracle_v.c", "sph_oracle_grav.c")]
     if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "liborc.so"], check=True, stdout=subprocess.DEVNULL)
     return path

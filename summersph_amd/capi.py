@@ -15,11 +15,12 @@ LIB_PATH = os.path.join(_PKG, "libsummersph_hip.so")
 _D = C.POINTER(C.c_double)
 
 FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha", "h", "omega"]
-KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h"]
+KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h", "gravity"]
 FLAG_REUSE_DENSITY = 1
 FLAG_VARIABLE_H = 2
 FLAG_NO_LDS_TILES = 4
 FLAG_LDS_TILE_EVAL = 8
+FLAG_SELF_GRAVITY = 16
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
@@ -40,7 +41,8 @@ class Params(C.Structure):
                 ("alpha_floor", C.c_double), ("alpha_decay", C.c_double), ("G", C.c_double),
                 ("dt_scale", C.c_double), ("dt_max", C.c_double), ("dt_min", C.c_double),
                 ("bounding_size", C.c_double), ("eta", C.c_double), ("h_tol", C.c_double),
-                ("h_max_length", C.c_double), ("h_min_length", C.c_double), ("h_iter_cap", C.c_double)]
+                ("h_max_length", C.c_double), ("h_min_length", C.c_double), ("h_iter_cap", C.c_double),
+                ("theta", C.c_double)]
 
 
 class Stats(C.Structure):

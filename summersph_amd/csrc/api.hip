@@ -45,6 +45,9 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max);
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
+    ctx_free(c, c->g_left); ctx_free(c, c->g_right); ctx_free(c, c->g_parent); ctx_free(c, c->g_leaf_parent);
+    ctx_free(c, c->g_prefix); ctx_free(c, c->g_flag); ctx_free(c, c->g_slot); ctx_free(c, c->g_lvl); ctx_free(c, c->g_rope);
+    ctx_free(c, c->g_leaf_rope); ctx_free(c, c->g_sum); ctx_free(c, c->g_leafA);
     c->msort_tmp_bytes = 0;
     c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
 }
@@ -77,15 +80,25 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     if (c->variable) {
         API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
+        API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
+    }
+    if (c->variable || c->gravity) {
         API_TRY(ctx_alloc(c, &c->mkeys, (size_t)cap, "octree keys"));
         API_TRY(ctx_alloc(c, &c->mkeys_alt, (size_t)cap, "octree keys (alt)"));
         API_TRY(ctx_alloc(c, &c->mvals, (size_t)cap, "octree vals"));
         API_TRY(ctx_alloc(c, &c->mvals_alt, (size_t)cap, "octree vals (alt)"));
-        API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
         size_t mt = 0;
         API_HIP(varh_sort_tmp_bytes(cap, &mt));
         c->msort_tmp_bytes = mt;
         API_TRY(ctx_alloc_bytes(c, &c->msort_tmp, mt ? mt : 1, "octree sort scratch"));
+    }
+    if (c->gravity) {
+        API_TRY(ctx_alloc(c, &c->g_left, (size_t)cap, "tree left")); API_TRY(ctx_alloc(c, &c->g_right, (size_t)cap, "tree right"));
+        API_TRY(ctx_alloc(c, &c->g_parent, (size_t)cap, "tree parent")); API_TRY(ctx_alloc(c, &c->g_leaf_parent, (size_t)cap, "leaf parent"));
+        API_TRY(ctx_alloc(c, &c->g_prefix, (size_t)cap, "tree prefix")); API_TRY(ctx_alloc(c, &c->g_flag, (size_t)cap, "tree flags"));
+        API_TRY(ctx_alloc(c, &c->g_slot, (size_t)cap, "leaf slots")); API_TRY(ctx_alloc(c, &c->g_lvl, (size_t)cap, "tree levels"));
+        API_TRY(ctx_alloc(c, &c->g_rope, (size_t)cap, "tree ropes")); API_TRY(ctx_alloc(c, &c->g_leaf_rope, (size_t)cap, "leaf ropes"));
+        API_TRY(ctx_alloc(c, &c->g_sum, (size_t)cap * 4, "node sums")); API_TRY(ctx_alloc(c, &c->g_leafA, (size_t)cap * 4, "leaf records"));
     }
     c->cap = cap;
     return SPH_OK;
@@ -106,6 +119,22 @@ void host_tables(int nq, std::vector<double> &w, std::vector<double> &dw) {
             const double t = 2.0 - q;
             w[i] = 0.25 * (t * t * t);
             dw[i] = -0.75 * (t * t);
+        }
+    }
+}
+
+void host_grav_table(int nq, std::vector<double> &g) {
+    // SUMMER_SPH.f90:81-101: spline-softened force factor, 1 outside the support
+    g.assign((size_t)nq + 1, 1.0);
+    const double dq = 2.0 / nq;
+    for (int i = 0; i <= nq; i++) {
+        const double q = i * dq;
+        if (q >= 0.0 && q <= 1.0) {
+            const double q3 = q * q * q, q5 = q3 * q * q, q6 = q5 * q;
+            g[i] = ((40.0 * q3) - (36.0 * q5) + (15.0 * q6)) / 30.0;
+        } else if (q > 1.0 && q <= 2.0) {
+            const double q3 = q * q * q, q4 = q3 * q, q5 = q4 * q, q6 = q5 * q;
+            g[i] = ((80.0 * q3) - (90.0 * q4) + (36.0 * q5) - (5 * q6) - 2) / 30.0;
         }
     }
 }
@@ -142,7 +171,7 @@ int do_density(sph_ctx *c) {
     if (!c->grid_valid) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
-        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
+        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         if (c->variable) {
             { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
             { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
@@ -166,6 +195,11 @@ int do_density(sph_ctx *c) {
 int do_forces(sph_ctx *c) {
     if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces: call sph_density first"; return SPH_ERR_STATE; }
     const PairConst pc = make_pair_const(c);
+    if (c->gravity) {                                   // particle_gravforces, [F]:825 -- before the sink and SPH terms
+        Timed t(c, SPH_K_GRAVITY);
+        if (!c->tree_valid) { API_TRY(gravity_tree_build(c)); c->tree_valid = true; }
+        API_HIP(launch_gravity(c));
+    }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
     { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc) : launch_forces(c, pc))); }
     c->force_passes++;
@@ -304,6 +338,7 @@ int sph_params_default(sph_params *p) {
     p->eta = 1.2; p->h_tol = 1e-3; p->h_max_length = 10.0;     // variable-h only (no reference defaults exist)
     p->h_min_length = (double)0.01f;          // Variable.f90:528
     p->h_iter_cap = 10.0;                     // Variable.f90:529
+    p->theta = 0.5;                           // :825
     return SPH_OK;
 }
 
@@ -330,6 +365,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if (!c) return SPH_ERR_NOMEM;
     c->p = *p;
     c->variable = (p->flags & SPH_FLAG_VARIABLE_H) != 0;
+    c->gravity = (p->flags & SPH_FLAG_SELF_GRAVITY) != 0;
     c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
     c->tiled_eval = c->tiled && (p->flags & SPH_FLAG_LDS_TILE_EVAL) != 0;
     c->packed_list = c->tiled;
@@ -344,6 +380,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->grav_tab, (size_t)p->nq + 1, "softening table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_pair, (size_t)2 * p->nq, "W pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_pair, (size_t)2 * p->nq, "dW pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->sink, (size_t)10 * MAX_SINKS, "sinks")) != SPH_OK) return fail(st);
@@ -354,6 +391,11 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->d_dt, 4, "dt")) != SPH_OK) return fail(st);
     std::vector<double> w, dw;
     host_tables(p->nq, w, dw);
+    {
+        std::vector<double> gt;
+        host_grav_table(p->nq, gt);
+        if (hipMemcpy(c->grav_tab, gt.data(), gt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SPH_ERR_HIP);
+    }
     std::vector<double> wp((size_t)2 * p->nq), dwp((size_t)2 * p->nq);
     for (int k = 0; k < p->nq; k++) { wp[2 * k] = w[k]; wp[2 * k + 1] = w[k + 1]; dwp[2 * k] = dw[k]; dwp[2 * k + 1] = dw[k + 1]; }
     if (hipMemcpy(c->w_pair, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
@@ -374,6 +416,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     resolve_timing(c);
     free_particle_arrays(c);
     ctx_free(c, c->cell_start); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
+    ctx_free(c, c->grav_tab);
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);

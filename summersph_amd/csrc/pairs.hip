@@ -268,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     if (!live) return;
 
     // zero_rates, then the gas side of sink_gravforces, [F]:567-576
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;   // [F]:824-825
     for (int s = 0; s < pc.ns; s++) {
         const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
         const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
@@ -365,6 +365,7 @@ PairConst make_pair_const(const sph_ctx *c) {
     pc.G = p.G; pc.gamma = p.gamma; pc.gamma_m1 = p.gamma_m1;
     pc.rcut2 = 4.0 * p.h * p.h * (1.0 + 1e-12);
     pc.ns = c->ns;
+    pc.grav = c->gravity ? 1 : 0;
     pc.kernel_pi = p.kernel_pi; pc.eta = p.eta; pc.h_tol = p.h_tol; pc.h_max_length = p.h_max_length;
     pc.h_min_length = p.h_min_length; pc.h_iter_cap = p.h_iter_cap; pc.dt_scale = p.dt_scale;
     if (c->variable) pc.visc_eps_h2 = p.visc_eps;        // multiplied by avg_len^2 per pair (Variable.f90:405)

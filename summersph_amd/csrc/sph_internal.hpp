@@ -39,6 +39,7 @@ struct PairConst {
     double rcut2;        // (2h)^2 (1 + 1e-12): filter only, the evaluation re-tests q <= 2
     int32_t nq;
     int32_t ns;          // sinks
+    int32_t grav;        // 1: ax, ay, az already hold the self-gravity term ([F]:825), continue from there
     // variable-h path
     double kernel_pi, eta, h_tol, h_max_length, h_min_length, h_iter_cap, dt_scale;
 };
@@ -87,6 +88,14 @@ struct sph_ctx {
     double *h_new = nullptr;         // scratch for calc_smoothing
     double h_max_glob = 0.0, h_mean = 0.0;
     double root_box[4] = {0, 0, 0, 0};   // octree root centre + edge ([V]:1007-1012)
+
+    // Barnes-Hut gas self-gravity (gravity.hip): binary radix tree over the octree path keys
+    bool gravity = false;
+    bool tree_valid = false;
+    int32_t *g_left = nullptr, *g_right = nullptr, *g_parent = nullptr, *g_leaf_parent = nullptr, *g_prefix = nullptr;
+    int32_t *g_flag = nullptr, *g_slot = nullptr, *g_lvl = nullptr, *g_rope = nullptr, *g_leaf_rope = nullptr;
+    double *g_sum = nullptr, *g_leafA = nullptr;     // 4 doubles per node / leaf
+    double *grav_tab = nullptr;                      // softening table, [F]:81-101
 
     // grid
     sph::GridDesc grid{};
@@ -171,6 +180,10 @@ hipError_t launch_dt_partial_only(sph_ctx *c);
 int nlist_build_tiled(sph_ctx *c);
 hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
+// self-gravity (gravity.hip)
+hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
+int gravity_tree_build(sph_ctx *c);
+hipError_t launch_gravity(sph_ctx *c);
 // variable-h path (varh.hip)
 hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)

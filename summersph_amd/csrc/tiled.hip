@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TB) void forces_tiled(GridDesc g, PairConst pc, con
     }
     if (!live) return;
     // zero_rates, then the gas side of sink_gravforces, [F]:567-576
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;   // [F]:824-825
     for (int s = 0; s < pc.ns; s++) {
         const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
         const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);

@@ -26,6 +26,7 @@ module sph_hip_binding
     integer(c_int32_t) :: nq, flags
     real(c_double) :: kernel_pi, visc_eps, alpha_floor, alpha_decay, G, dt_scale, dt_max, dt_min, bounding_size
     real(c_double) :: eta, h_tol, h_max_length, h_min_length, h_iter_cap     ! variable-h path only
+    real(c_double) :: theta                                                   ! self-gravity opening angle
   end type sph_params
 
   type, bind(C) :: sph_stats

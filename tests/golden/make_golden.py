@@ -106,6 +106,12 @@ def main():
         discns = disc[:-1]
         p = os.path.join(td, "discns.txt"); txtio.write_ic(p, discns)
         np.savez(os.path.join(HERE, "disc3000ns_eval.npz"), ic=discns, **run("eval", p))
+        # ---- accretion + boundary cull: inner edge inside the sink's reach, three particles outside the box ----
+        acc = ic.keplerian_disc(2000, seed=606, r_in=0.6, nngb=30.0)
+        acc[5, 0:3] = [1600.0, 3.0, 0.5]; acc[77, 0:3] = [-20.0, -1700.0, 1.0]; acc[1500, 0:3] = [10.0, 5.0, 1501.0]
+        p = os.path.join(td, "acc.txt"); txtio.write_ic(p, acc)
+        t_a = keep_steps(run("traj", p, 3, "full"), {1, 2, 3})
+        np.savez(os.path.join(HERE, "acc2000_traj.npz"), ic=acc, **{"full_" + k: v for k, v in t_a.items()})
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):
             print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")
