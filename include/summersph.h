@@ -78,6 +78,8 @@ typedef struct sph_params {
                                    h update after every step.  Upload h with sph_upload_field. */
 #define SPH_FLAG_SELF_GRAVITY 16 /* find_forces WITH the Barnes-Hut gas self-gravity term (particle_gravforces,
                                    [F]:249-290, 825): sph_forces then equals find_forces as it is.  Single GPU. */
+#define SPH_FLAG_ACCRETE_CULL 32 /* sph_step / sph_run also do the end-of-step sink accretion and boundary cull
+                                   of simulate() ([F]:919-920): the particle count may shrink (sph_count) */
 #define SPH_FLAG_NO_LDS_TILES 4  /* fixed-h path: build the neighbour list with per-lane gathers (pairs.hip)
                                    instead of LDS-staged tiles (tiled.hip); A/B measurements        */
 #define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
@@ -147,6 +149,9 @@ int sph_set_sinks(sph_ctx *ctx, int32_t ns, const double *sx, const double *sy, 
 int sph_get_sinks(sph_ctx *ctx, int32_t ns, double *sx, double *sy, double *sz,
                   double *svx, double *svy, double *svz, double *sm,
                   double *sax, double *say, double *saz);
+/* accretion radii of the sinks ([F]:694: 3.5, [V]:830: 5.0 for file sinks, 0 for the dummy sink); the
+ * defaults set by sph_set_sinks are 3.5 (fixed h) / 5.0 (variable h) */
+int sph_set_sink_radii(sph_ctx *ctx, int32_t ns, const double *radius);
 int64_t sph_count(const sph_ctx *ctx);
 /* one field in the caller's particle order, host or device source (e.g. SPH_F_H after sph_upload) */
 int sph_upload_field(sph_ctx *ctx, int field, const double *host, int64_t n);
@@ -163,6 +168,12 @@ int sph_kick(sph_ctx *ctx, double dt);
 int sph_drift(sph_ctx *ctx, double dt);
 /* get_next_timestep ([F]:831-860): in/out dt                                             */
 int sph_next_dt(sph_ctx *ctx, double *dt);
+/* initiate_sink_accretion (only if a sink has mass, [F]:919) + check_bounds ([F]:920) on the current
+ * positions: removes accreted / escaped particles on the device, merges accreted mass and momentum
+ * into the sinks.  Survivors keep their relative order: the caller's numbering becomes the rank among
+ * survivors, as after the reference's pack().  Needs the grid of the current positions (call it after
+ * sph_density / sph_forces / sph_kick, before the next sph_drift).                               */
+int sph_accrete_and_cull(sph_ctx *ctx, int64_t *n_removed);
 /* variable-h only: calc_smoothing ([V]:515-546) on the neighbour structure of the last evaluation */
 int sph_update_h(sph_ctx *ctx);
 /* one iteration of simulate's loop body, [F]:889-916 (variable-h: [V]:1120-1152 incl. the h update): density, forces, kick, drift,

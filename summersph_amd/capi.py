@@ -21,9 +21,11 @@ FLAG_VARIABLE_H = 2
 FLAG_NO_LDS_TILES = 4
 FLAG_LDS_TILE_EVAL = 8
 FLAG_SELF_GRAVITY = 16
+FLAG_ACCRETE_CULL = 32
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
+    "sph_set_sink_radii", "sph_accrete_and_cull",
     "sph_params_default", "sph_params_default_variable", "sph_upload_field", "sph_upload_field_dev", "sph_update_h",
     "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
     "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
@@ -104,6 +106,8 @@ def load():
     lib.sph_upload_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.sph_upload_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.sph_update_h.argtypes = [C.c_void_p]
+    lib.sph_set_sink_radii.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.sph_accrete_and_cull.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.sph_set_owned.argtypes = [C.c_void_p, C.c_int64]
     lib.sph_set_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.sph_scatter_field_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
@@ -195,6 +199,14 @@ class Context:
         arrs = [np.ascontiguousarray(sinks[k], dtype=np.float64) for k in "x y z vx vy vz m".split()]
         self._ck(self.lib.sph_set_sinks(self._h, arrs[0].size, *[_hp(a) for a in arrs]))
         self.ns = int(arrs[0].size)
+        if sinks.get("radius") is not None:
+            r = np.ascontiguousarray(sinks["radius"], dtype=np.float64)
+            self._ck(self.lib.sph_set_sink_radii(self._h, r.size, _hp(r)))
+
+    def accrete_and_cull(self) -> int:
+        r = C.c_int64(0)
+        self._ck(self.lib.sph_accrete_and_cull(self._h, C.byref(r)))
+        return int(r.value)
 
     def get_sinks(self) -> dict:
         ns = self.ns

@@ -1,0 +1,242 @@
+// accrete.hip -- sink accretion and boundary cull on the device (the particle set shrinks).
+//
+// Replaces (citations: /root/reference/SUMMER_SPH.f90 "[F]"; "SUMMER_SPH - Variable.f90" "[V]")
+//   initiate_sink_accretion + sink2gasdists + pack_sinks   [F]:484-556  ([V]:616-688)
+//   check_bounds                                           [F]:471-482  ([V]:599-614, gas part)
+//
+// The reference decides accretion on its octree: a sink's walk descends while the node centre is within
+// radius + edge/2 of the sink on every axis, and at a one-particle leaf it applies ITS distance rule --
+// [F]: leaf centre within 2 radius + edge/2, then sum_k sqrt(centre_k^2 - sink_k^2) < radius (a quirk of
+//      the reference: it uses the LEAF CENTRE, and a negative argument gives NaN = "not accreted");
+// [V]: leaf centre within radius + edge/2, then sum_k |x_k - sink_k| < radius.
+// Both need the particle's chain of octree boxes, which is replayed here from the particle's path key
+// (same keys as gravity.hip / varh.hip) and its leaf level (longest common prefix with its sorted
+// neighbours + 1).  Survivors keep their relative order (the reference's pack()), i.e. the caller's
+// particle numbering after the call is "rank among survivors".
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cmath>
+
+#include "pair_common.hpp"
+
+namespace sph {
+
+namespace {
+
+constexpr int AB = 256;
+constexpr int LEVELS = 21;
+
+struct RootBox { double c[3]; double size; };
+
+__global__ __launch_bounds__(AB) void acc_keys(RootBox rb, const double4 *__restrict__ drec, int64_t n,
+                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * AB + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = drec[i];
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    uint64_t key = 0;
+    for (int l = 0; l < LEVELS; l++) {
+        const int bx = p.x > cx, by = p.y > cy, bz = p.z > cz;
+        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+        const double q = 0.25 * size;
+        cx = cx + (bx ? q : -q); cy = cy + (by ? q : -q); cz = cz + (bz ? q : -q);
+        size = size * 0.5;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ int common_levels(uint64_t a, uint64_t b) {
+    const uint64_t x = a ^ b;
+    if (x == 0) return LEVELS;
+    return (__clzll((long long)x) - 1) / 3;
+}
+
+// keep[id] = 1 unless accreted by some sink or outside the box.  acc[slot] = bit mask of accreting sinks.
+__global__ __launch_bounds__(AB) void acc_mark(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                               int64_t n, const double4 *__restrict__ drec, const int32_t *__restrict__ orig,
+                                               const double *__restrict__ sink, const double *__restrict__ srad, int ns, int variant,
+                                               int do_accrete, double bound, int32_t *__restrict__ keep,
+                                               unsigned long long *__restrict__ accmask) {
+    const int64_t s = (int64_t)blockIdx.x * AB + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t key = keys[s];
+    int cp = 0;
+    if (s > 0) cp = max(cp, common_levels(key, keys[s - 1]));
+    if (s + 1 < n) cp = max(cp, common_levels(key, keys[s + 1]));
+    const int level = n == 1 ? 0 : min(cp + 1, LEVELS);
+    const uint32_t slot = vals[s];
+    const double4 p = drec[slot];
+    unsigned long long mask = 0ull;
+    if (do_accrete) {
+        for (int k = 0; k < ns; k++) {
+            const double sx = sink[0 * MAX_SINKS + k], sy = sink[1 * MAX_SINKS + k], sz = sink[2 * MAX_SINKS + k];
+            const double rad = srad[k];
+            double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+            bool reached = true;
+            for (int l = 1; l <= level; l++) {          // ancestors: levels 0 .. level-1 hold more than one particle
+                const double lim = rad + size / 2.0;                                         // [F]:529
+                if (!(fabs(cx - sx) < lim && fabs(cy - sy) < lim && fabs(cz - sz) < lim)) { reached = false; break; }
+                const int ch = (int)((key >> (3 * (LEVELS - l))) & 7);
+                const double q = 0.25 * size;
+                cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+                size = size * 0.5;
+            }
+            if (!reached) continue;
+            const double lim = (variant ? rad : 2 * rad) + size / 2.0;                       // [F]:536 / [V]:668
+            if (!(fabs(cx - sx) < lim && fabs(cy - sy) < lim && fabs(cz - sz) < lim)) continue;
+            double dr;
+            if (variant) dr = sqrt((p.x - sx) * (p.x - sx)) + sqrt((p.y - sy) * (p.y - sy)) + sqrt((p.z - sz) * (p.z - sz));   // [V]:669
+            else dr = sqrt(cx * cx - sx * sx) + sqrt(cy * cy - sy * sy) + sqrt(cz * cz - sz * sz);                             // [F]:537
+            if (dr < rad) mask |= 1ull << k;
+        }
+    }
+    accmask[slot] = mask;
+    const bool inside = fabs(p.x) <= bound && fabs(p.y) <= bound && fabs(p.z) <= bound;       // [F]:478
+    keep[orig[slot]] = (mask == 0ull && inside) ? 1 : 0;
+}
+
+__device__ __forceinline__ double wave_sumd(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// per sink: sum of m, m x, m v over its accreted particles (two stages, fixed order)
+__global__ __launch_bounds__(AB) void acc_sums_partial(int64_t n, int k, const unsigned long long *__restrict__ accmask,
+                                                       const double4 *__restrict__ drec, const double *__restrict__ vx,
+                                                       const double *__restrict__ vy, const double *__restrict__ vz,
+                                                       double *__restrict__ part) {
+    __shared__ double sm[7][AB / WAVE];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * AB + threadIdx.x; i < n; i += (int64_t)gridDim.x * AB) {
+        if ((accmask[i] >> k) & 1ull) {
+            const double4 p = drec[i];
+            v[0] += p.w; v[1] += p.w * p.x; v[2] += p.w * p.y; v[3] += p.w * p.z;
+            v[4] += p.w * vx[i]; v[5] += p.w * vy[i]; v[6] += p.w * vz[i];
+        }
+    }
+    for (int q = 0; q < 7; q++) {
+        const double r = wave_sumd(v[q]);
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double r = 0.0;
+        for (int w = 0; w < AB / WAVE; w++) r += sm[threadIdx.x][w];
+        part[(size_t)blockIdx.x * 7 + threadIdx.x] = r;
+    }
+}
+
+// [F]:497-508: new_mass, position and velocity become mass-weighted means, mass grows
+__global__ void acc_sink_update(int k, const double *__restrict__ part, int nb, double *__restrict__ sink) {
+    if (threadIdx.x != 0) return;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; b++)
+        for (int q = 0; q < 7; q++) v[q] += part[(size_t)b * 7 + q];
+    const double m0 = sink[6 * MAX_SINKS + k];
+    const double nm = m0 + v[0];
+    for (int a = 0; a < 3; a++) {
+        sink[a * MAX_SINKS + k] = (m0 * sink[a * MAX_SINKS + k] + v[1 + a]) / nm;
+        sink[(3 + a) * MAX_SINKS + k] = (m0 * sink[(3 + a) * MAX_SINKS + k] + v[4 + a]) / nm;
+    }
+    sink[6 * MAX_SINKS + k] = m0 + v[0];
+}
+
+struct CompactArgs {
+    const double *src[10];
+    double *dst[10];
+    int nf;
+};
+
+// survivors, in the caller's order: new id = number of survivors before it
+__global__ __launch_bounds__(AB) void acc_compact(CompactArgs a, const int32_t *__restrict__ keep, const int32_t *__restrict__ pos,
+                                                  const int32_t *__restrict__ inv, int64_t n) {
+    const int64_t id = (int64_t)blockIdx.x * AB + threadIdx.x;
+    if (id >= n || !keep[id]) return;
+    const int32_t slot = inv[id], o = pos[id];
+    for (int f = 0; f < a.nf; f++) a.dst[f][o] = a.src[f][slot];
+}
+
+}  // namespace
+
+#define AC_CHECK(expr)                                                      \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) {                                             \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+            return SPH_ERR_HIP;                                             \
+        }                                                                   \
+    } while (0)
+
+// requires a valid grid (bbox, drec, orig/inv of the current positions).  On return the context holds only
+// the survivors, in the caller's order (like a fresh upload); *removed = how many particles left.
+int accrete_and_cull(sph_ctx *c, int64_t *removed) {
+    const int64_t n = c->n;
+    *removed = 0;
+    if (n == 0) return SPH_OK;
+    RootBox rb;
+    double size = 0.0;
+    for (int a = 0; a < 3; a++) {
+        rb.c[a] = (c->bbox[3 + a] + c->bbox[a]) / 2.0;
+        size = std::max(size, c->bbox[3 + a] - c->bbox[a]);
+    }
+    rb.size = size;
+    const unsigned gb = (unsigned)((n + AB - 1) / AB);
+    const double4 *drec = reinterpret_cast<const double4 *>(c->drec);
+    // sinks' masses decide whether accretion runs at all ([F]:919): read them (tiny)
+    std::vector<double> sm((size_t)MAX_SINKS);
+    AC_CHECK(hipMemcpyAsync(sm.data(), c->sink + (size_t)6 * MAX_SINKS, sizeof(double) * MAX_SINKS, hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    bool any_mass = false;
+    for (int k = 0; k < c->ns; k++) any_mass |= sm[k] > 0.0;
+
+    acc_keys<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, drec, n, c->mkeys, c->mvals);
+    size_t tmp = c->msort_tmp_bytes;
+    AC_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+    int32_t *keep = reinterpret_cast<int32_t *>(c->keys);          // the cell-key buffers are free between grid builds
+    int32_t *pos = reinterpret_cast<int32_t *>(c->keys_alt);
+    unsigned long long *accmask = reinterpret_cast<unsigned long long *>(c->scratch);
+    acc_mark<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, drec, c->orig, c->sink, c->sink_radius, c->ns,
+                                                   c->variable ? 1 : 0, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
+    AC_CHECK(hipGetLastError());
+    if (any_mass) {
+        const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
+        for (int k = 0; k < c->ns; k++) {
+            acc_sums_partial<<<dim3(nb), dim3(AB), 0, c->stream>>>(n, k, accmask, drec, c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->sink_part);
+            acc_sink_update<<<dim3(1), dim3(64), 0, c->stream>>>(k, c->sink_part, nb, c->sink);
+        }
+        AC_CHECK(hipGetLastError());
+    }
+    // exclusive scan of keep[] over original ids -> new ids
+    size_t sb = 0;
+    AC_CHECK(rocprim::exclusive_scan(nullptr, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
+    if (sb > c->sort_tmp_bytes) { c->err = "accrete: scan scratch too small"; return SPH_ERR_NOMEM; }
+    AC_CHECK(rocprim::exclusive_scan(c->sort_tmp, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
+    int32_t last[2];
+    AC_CHECK(hipMemcpyAsync(&last[0], pos + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipMemcpyAsync(&last[1], keep + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t n_new = (int64_t)last[0] + last[1];
+    if (n_new == n) return SPH_OK;                     // nobody left: sorted state stays as it is
+    CompactArgs ca{};
+    for (int k = 0; k < 9; k++) { ca.src[k] = c->f[k]; ca.dst[k] = c->f_alt[k]; }
+    ca.nf = 9;
+    if (c->variable) { ca.src[9] = c->f[SPH_F_H]; ca.dst[9] = c->f_alt[9]; ca.nf = 10; }
+    acc_compact<<<dim3(gb), dim3(AB), 0, c->stream>>>(ca, keep, pos, c->inv, n);
+    AC_CHECK(hipGetLastError());
+    for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
+    if (c->variable) std::swap(c->f[SPH_F_H], c->f_alt[9]);
+    c->n = n_new;
+    c->n_owned = n_new;
+    AC_CHECK(launch_iota(c, c->orig, n_new));
+    AC_CHECK(launch_iota(c, c->inv, n_new));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = false;
+    *removed = n - n_new;
+    return SPH_OK;
+}
+
+}  // namespace sph

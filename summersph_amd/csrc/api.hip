@@ -82,7 +82,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
         API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
     }
-    if (c->variable || c->gravity) {
+    {   // octree path keys: leaf boxes (variable h), self-gravity tree, accretion
         API_TRY(ctx_alloc(c, &c->mkeys, (size_t)cap, "octree keys"));
         API_TRY(ctx_alloc(c, &c->mkeys_alt, (size_t)cap, "octree keys (alt)"));
         API_TRY(ctx_alloc(c, &c->mvals, (size_t)cap, "octree vals"));
@@ -171,6 +171,7 @@ int do_density(sph_ctx *c) {
     if (!c->grid_valid) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
+        c->order_valid = true;
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         if (c->variable) {
             { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
@@ -218,7 +219,7 @@ int do_kick(sph_ctx *c, double dt, bool dev) {
 int do_drift(sph_ctx *c, double dt, bool dev) {
     Timed t(c, SPH_K_DRIFT);
     API_HIP(launch_drift(c, dt, dev));
-    c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
+    c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; c->order_valid = false;
     return SPH_OK;
 }
 
@@ -247,6 +248,12 @@ int do_update_h(sph_ctx *c) {
     return SPH_OK;
 }
 
+int do_accrete(sph_ctx *c, int64_t *removed) {
+    if (!c->order_valid) { c->err = "sph_accrete_and_cull: needs the grid of the current positions (call sph_density first)"; return SPH_ERR_STATE; }
+    if (c->n_owned != c->n) { c->err = "sph_accrete_and_cull: not available with ghost particles"; return SPH_ERR_STATE; }
+    return accrete_and_cull(c, removed);
+}
+
 int one_step_device_dt(sph_ctx *c) {
     // SUMMER_SPH.f90:889-916
     API_TRY(do_density(c));
@@ -258,6 +265,10 @@ int one_step_device_dt(sph_ctx *c) {
     API_TRY(do_kick(c, 0.0, true));
     { Timed t(c, SPH_K_DT); API_HIP(launch_next_dt(c, true)); }
     if (c->variable) API_TRY(do_update_h(c));          // Variable.f90:1152
+    if (c->p.flags & SPH_FLAG_ACCRETE_CULL) {          // SUMMER_SPH.f90:919-920
+        int64_t removed = 0;
+        API_TRY(do_accrete(c, &removed));
+    }
     return SPH_OK;
 }
 
@@ -384,6 +395,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->w_pair, (size_t)2 * p->nq, "W pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_pair, (size_t)2 * p->nq, "dW pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->sink, (size_t)10 * MAX_SINKS, "sinks")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->sink_radius, (size_t)MAX_SINKS, "sink radii")) != SPH_OK) return fail(st);
     c->sink_blocks = 512;
     if ((st = ctx_alloc(c, &c->sink_part, (size_t)c->sink_blocks * MAX_SINKS * 3, "sink partials")) != SPH_OK) return fail(st);
     c->dt_blocks = 1024;
@@ -416,7 +428,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     resolve_timing(c);
     free_particle_arrays(c);
     ctx_free(c, c->cell_start); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
-    ctx_free(c, c->grav_tab);
+    ctx_free(c, c->grav_tab); ctx_free(c, c->sink_radius);
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -445,7 +457,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     API_HIP(launch_iota(c, c->inv, n));
     if (c->variable) API_HIP(launch_fill(c, c->f[SPH_F_H], c->p.h, n));    // until sph_upload_field(SPH_F_H) sets it
     API_HIP(hipStreamSynchronize(c->stream));
-    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = false;
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
     return SPH_OK;
 }
 
@@ -472,6 +484,8 @@ int sph_set_sinks(sph_ctx *c, int32_t ns, const double *sx, const double *sy, co
     for (int k = 0; k < 7; k++) for (int s = 0; s < ns; s++) buf[(size_t)k * MAX_SINKS + s] = src[k][s];
     API_HIP(hipStreamSynchronize(c->stream));
     API_HIP(hipMemcpy(c->sink, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> rad((size_t)MAX_SINKS, c->variable ? 5.0 : 3.5);      // Variable.f90:830 / SUMMER_SPH.f90:694
+    API_HIP(hipMemcpy(c->sink_radius, rad.data(), rad.size() * sizeof(double), hipMemcpyHostToDevice));
     c->ns = ns;
     c->rates_valid = false;
     return SPH_OK;
@@ -578,12 +592,30 @@ static int upload_field_impl(sph_ctx *c, int field, const double *src, int64_t n
     API_HIP(launch_scatter_fields(c, 1, &f, 0, n, dsrc));
     API_HIP(hipStreamSynchronize(c->stream));
     if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) { c->grid_valid = false; c->rho_valid = false; }
+    if (field <= SPH_F_Z) c->order_valid = false;
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
     return SPH_OK;
 }
 
 int sph_upload_field(sph_ctx *c, int field, const double *host, int64_t n) { return upload_field_impl(c, field, host, n, true); }
 int sph_upload_field_dev(sph_ctx *c, int field, const double *d_vals, int64_t n) { return upload_field_impl(c, field, d_vals, n, false); }
+
+int sph_set_sink_radii(sph_ctx *c, int32_t ns, const double *radius) {
+    if (!c || ns != c->ns || (ns > 0 && !radius)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(hipStreamSynchronize(c->stream));
+    if (ns > 0) API_HIP(hipMemcpy(c->sink_radius, radius, (size_t)ns * sizeof(double), hipMemcpyHostToDevice));
+    return SPH_OK;
+}
+
+int sph_accrete_and_cull(sph_ctx *c, int64_t *n_removed) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    int64_t r = 0;
+    const int st = do_accrete(c, &r);
+    if (n_removed) *n_removed = r;
+    return st;
+}
 
 int sph_update_h(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_update_h(c); }
 

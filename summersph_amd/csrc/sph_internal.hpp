@@ -120,6 +120,7 @@ struct sph_ctx {
     // sinks on the device: 10 arrays of MAX_SINKS doubles: x y z vx vy vz m ax ay az
     int32_t ns = 0;
     double *sink = nullptr;
+    double *sink_radius = nullptr;   // MAX_SINKS accretion radii
     double *sink_part = nullptr;     // per-block partial sums for the sink accelerations
     int32_t sink_blocks = 0;
 
@@ -127,6 +128,7 @@ struct sph_ctx {
     double *d_dt = nullptr;
     double *dt_part = nullptr; int32_t dt_blocks = 0;
 
+    bool order_valid = false;    // sorted order, drec, bbox, orig/inv match the current positions
     bool grid_valid = false;     // sorted order + cell table + neighbour list match positions
     bool rho_valid = false;      // rho matches positions and masses
     bool eos_valid = false;      // P, c, frec match rho, u, alpha, v
@@ -184,6 +186,8 @@ hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
 hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
 int gravity_tree_build(sph_ctx *c);
 hipError_t launch_gravity(sph_ctx *c);
+// accretion + boundary cull (accrete.hip)
+int accrete_and_cull(sph_ctx *c, int64_t *removed);
 // variable-h path (varh.hip)
 hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)

@@ -69,3 +69,38 @@ def test_gravity_vs_oracle_tree_walk_100k(capi):
         mine = a_full[k] - ref.field(f)
         assert np.max(np.abs(mine - ga[k])) <= 1e-9 * np.max(np.abs(ga[k])), f
     ctx.close(); ref.close()
+
+
+def test_accretion_and_cull_vs_reference_fixture(capi):
+    """simulate()'s loop body as it is: self-gravity, accretion by the sink, boundary cull (particle count
+    shrinks) -- 3 steps against the real reference"""
+    g = load_golden("acc2000_traj")
+    ctx, gas, sinks = make_ctx(capi, g["ic"], flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    dts, t, ns = [1e-2], 0.0, [ctx.n]
+    for k in range(1, 4):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt); ns.append(ctx.n)
+        p = f"full_s{k}_"
+        assert ctx.n == g[p + "x"].size
+        for f in "x y z vx vy vz u m alpha".split():
+            assert rel_err(ctx.field(f), g[p + f]) <= 1e-11, (k, f)
+        s = ctx.get_sinks()
+        assert abs(s["m"][0] - g[p + "sm"][0]) <= 1e-15 and abs(s["x"][0] - g[p + "sx"][0]) <= 1e-12
+    assert ns == [int(v) for v in g["full_n_seq"]] and ns[1] == ns[0] - 4
+    assert dts == list(g["full_dt_seq"])
+    ctx.close()
+
+
+def test_accrete_explicit_call_and_order(capi):
+    """explicit call; survivors keep their relative order (pack semantics)"""
+    g = load_golden("acc2000_traj")
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    ctx.density()
+    removed = ctx.accrete_and_cull()
+    assert removed >= 3 and ctx.n == gas["x"].size - removed
+    x_new = ctx.field("x")
+    keep = np.isin(gas["x"], x_new)
+    assert np.array_equal(gas["x"][keep], x_new)
+    ctx.density(); ctx.forces()          # the shrunken set evaluates fine
+    assert np.all(np.isfinite(ctx.field("ax")))
+    ctx.close()
