@@ -1,6 +1,8 @@
 ! run_sph_hip.f90 -- command-line front end of the Fortran host.
 !
-!   run_sph_hip [ic.txt] [max_steps] [final_snapshot.txt]
+!   run_sph_hip [ic.txt] [max_steps] [final_snapshot.txt] [sph]
+!
+! A fourth argument "sph" leaves out gas self-gravity, accretion and the boundary cull.
 !
 ! With no arguments it behaves like the reference program (SUMMER_SPH.f90:934-955): reads
 ! 'disc_12000_2.txt' and runs to t = 1000 writing saveN.txt files.  With max_steps it runs that
@@ -13,6 +15,7 @@ program run_sph_hip
   type(sink), allocatable :: sinks(:)
   real(dp), allocatable :: dts(:)
   integer :: nsteps, k
+  logical :: only_sph
 
   filename = 'disc_12000_2.txt'
   if (command_argument_count() >= 1) call get_command_argument(1, filename)
@@ -22,7 +25,12 @@ program run_sph_hip
   if (command_argument_count() >= 2) then
     call get_command_argument(2, arg)
     read(arg, *) nsteps
-    call simulate(bodies, sinks, max_steps=nsteps, quiet=.true., dt_log=dts)
+    only_sph = .false.
+    if (command_argument_count() >= 4) then
+      call get_command_argument(4, arg)
+      only_sph = trim(arg) == 'sph'
+    end if
+    call simulate(bodies, sinks, max_steps=nsteps, quiet=.true., dt_log=dts, sph_only=only_sph)
     do k = 0, ubound(dts, 1)
       write(*, '(A,I0,1X,ES25.17E3)') 'dt ', k, dts(k)
     end do

@@ -14,12 +14,19 @@ module sph_hip_binding
   public :: sph_download_field, sph_download_state, sph_get_stats, sph_get_bbox, sph_synchronize
   public :: SPH_OK, SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA
   public :: SPH_F_RHO, SPH_F_P, SPH_F_C, SPH_F_AX, SPH_F_AY, SPH_F_AZ, SPH_F_DU, SPH_F_DALPHA
+  public :: sph_set_sink_radii, sph_accrete_and_cull, sph_upload_field, sph_update_h, sph_params_default_variable
+  public :: SPH_F_H, SPH_F_OMEGA
+  public :: SPH_FLAG_REUSE_DENSITY, SPH_FLAG_VARIABLE_H, SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL
   public :: c_message
 
   integer(c_int), parameter :: SPH_OK = 0
   integer(c_int), parameter :: SPH_F_X = 0, SPH_F_Y = 1, SPH_F_Z = 2, SPH_F_VX = 3, SPH_F_VY = 4, SPH_F_VZ = 5
   integer(c_int), parameter :: SPH_F_U = 6, SPH_F_M = 7, SPH_F_ALPHA = 8, SPH_F_RHO = 9, SPH_F_P = 10, SPH_F_C = 11
   integer(c_int), parameter :: SPH_F_AX = 12, SPH_F_AY = 13, SPH_F_AZ = 14, SPH_F_DU = 15, SPH_F_DALPHA = 16
+
+  integer(c_int), parameter :: SPH_F_H = 17, SPH_F_OMEGA = 18
+  integer(c_int32_t), parameter :: SPH_FLAG_REUSE_DENSITY = 1, SPH_FLAG_VARIABLE_H = 2, SPH_FLAG_SELF_GRAVITY = 16
+  integer(c_int32_t), parameter :: SPH_FLAG_ACCRETE_CULL = 32
 
   type, bind(C) :: sph_params
     real(c_double) :: h, gamma, gamma_m1
@@ -92,6 +99,41 @@ module sph_hip_binding
       type(c_ptr), value :: ctx
       integer(c_int32_t), value :: ns
       real(c_double), intent(out) :: sx(*), sy(*), sz(*), svx(*), svy(*), svz(*), sm(*), sax(*), say(*), saz(*)
+    end function
+
+    integer(c_int) function sph_params_default_variable(p) bind(C, name='sph_params_default_variable')
+      import :: c_int, sph_params
+      type(sph_params), intent(out) :: p
+    end function
+
+    ! sink%radius (:694)
+    integer(c_int) function sph_set_sink_radii(ctx, ns, radius) bind(C, name='sph_set_sink_radii')
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: ns
+      real(c_double), intent(in) :: radius(*)
+    end function
+
+    ! initiate_sink_accretion + check_bounds (:919-920)
+    integer(c_int) function sph_accrete_and_cull(ctx, n_removed) bind(C, name='sph_accrete_and_cull')
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), intent(out) :: n_removed
+    end function
+
+    ! one field in the caller's particle order (e.g. the smoothing lengths of the variable-h variant)
+    integer(c_int) function sph_upload_field(ctx, field, host, n) bind(C, name='sph_upload_field')
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: field
+      real(c_double), intent(in) :: host(*)
+      integer(c_int64_t), value :: n
+    end function
+
+    ! calc_smoothing of the variable-h variant
+    integer(c_int) function sph_update_h(ctx) bind(C, name='sph_update_h')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
     end function
 
     integer(c_int64_t) function sph_count(ctx) bind(C, name='sph_count')

@@ -8,10 +8,10 @@
 ! Everything numerically heavy happens on the GPU through sph_hip_binding; this module only
 ! moves data across the boundary and keeps the book-keeping of the time loop.
 !
+! The device does everything simulate() does per step: density, EOS, Barnes-Hut gas self-gravity,
+! sink gravity, SPH forces, kicks, drift, dt control, sink accretion and the boundary cull (the
+! particle count may shrink; bodies is re-sized when that happens).
 ! Deliberate differences to the reference (see DESIGN.md "host"):
-!   * Barnes-Hut gas self-gravity (particle_gravforces, :249-290) and sink accretion
-!     (:484-556) are not part of this round's scope; the boundary cull (:471-482) is done
-!     here on the host when a particle leaves the box.
 !   * make_save writes one record per line with an explicit format (the reference's
 !     list-directed output wraps lines under flang) and replaces an existing file.
 !   * simulate takes optional arguments (end time, step limit, quiet) for testing.
@@ -202,6 +202,7 @@ contains
     s(:, 7) = sinks%mass
     call check(ctx, sph_set_sinks(ctx, int(ns, c_int32_t), s(:, 1), s(:, 2), s(:, 3), s(:, 4), s(:, 5), s(:, 6), s(:, 7)), &
                'sph_set_sinks')
+    call check(ctx, sph_set_sink_radii(ctx, int(ns, c_int32_t), sinks%radius), 'sph_set_sink_radii')
   end subroutine push_state
 
   subroutine pull_state(ctx, bodies, sinks, with_derived)
@@ -240,6 +241,7 @@ contains
     do i = 1, ns
       sinks(i)%position = s(i, 1:3)
       sinks(i)%velocity = s(i, 4:6)
+      sinks(i)%mass = s(i, 7)
       sinks(i)%acceleration = s(i, 8:10)
     end do
   end subroutine pull_state
@@ -248,13 +250,14 @@ contains
   ! The time loop.  Per step: density, forces, kick, drift, density, forces, kick, t += dt,
   ! next dt -- one sph_step call.  Saves every end_time/1000 of simulated time.
   ! ------------------------------------------------------------------------------------------
-  subroutine simulate(bodies, sinks, end_time_in, max_steps, quiet, device, dt_log)
+  subroutine simulate(bodies, sinks, end_time_in, max_steps, quiet, device, dt_log, sph_only)
     type(particle), allocatable, intent(inout) :: bodies(:)
     type(sink), intent(inout) :: sinks(:)
     real(dp), intent(in), optional :: end_time_in
     integer, intent(in), optional :: max_steps, device
     logical, intent(in), optional :: quiet
     real(dp), allocatable, intent(out), optional :: dt_log(:)
+    logical, intent(in), optional :: sph_only     ! .true.: leave out self-gravity, accretion and the cull
 
     type(c_ptr) :: ctx
     type(sph_params) :: prm
@@ -262,8 +265,7 @@ contains
     real(dp) :: end_time, next_save, save_every
     real(dp), allocatable :: dts(:)
     integer :: step, save_no, step_limit, dev, i
-    logical :: talk, outside
-    type(particle), allocatable :: kept(:)
+    logical :: talk
 
     end_time = 1000.0_dp
     if (present(end_time_in)) end_time = end_time_in
@@ -276,6 +278,11 @@ contains
 
     call check(c_null_ptr, sph_params_default(prm), 'sph_params_default')
     prm%h = smoothing
+    ! find_forces as it is (with the gas self-gravity term) + end-of-step accretion and cull, [F]:825,919-920
+    prm%flags = ior(SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL)
+    if (present(sph_only)) then
+      if (sph_only) prm%flags = 0
+    end if
     prm%bounding_size = bounding_size
     call check(c_null_ptr, sph_ctx_create(prm, int(dev, c_int), ctx), 'sph_ctx_create')
     call push_state(ctx, bodies, sinks)
@@ -302,13 +309,10 @@ contains
       step = step + 1
       if (step <= ubound(dts, 1)) dts(step) = dt
 
-      ! boundary cull (check_bounds): rare, so it is done on the host when it triggers
-      call pull_positions_outside(ctx, size(bodies), outside)
-      if (outside) then
-        call pull_state(ctx, bodies, sinks, .false.)
-        kept = pack(bodies, [(all(abs(bodies(i)%position) <= bounding_size), i = 1, size(bodies))])
-        call move_alloc(kept, bodies)
-        call push_state(ctx, bodies, sinks)
+      ! accretion / cull happened on the device: follow the particle count
+      if (int(sph_count(ctx)) /= size(bodies)) then
+        deallocate(bodies)
+        allocate(bodies(int(sph_count(ctx))))
       end if
     end do
 
@@ -323,16 +327,4 @@ contains
     call check(ctx, sph_ctx_destroy(ctx), 'sph_ctx_destroy')
   end subroutine simulate
 
-  ! .true. if any particle has left the [-bounding_size, bounding_size]^3 box.  After sph_step the
-  ! library's grid bounding box is that of the current positions, so no download is needed.
-  subroutine pull_positions_outside(ctx, n, outside)
-    type(c_ptr), intent(in) :: ctx
-    integer, intent(in) :: n
-    logical, intent(out) :: outside
-    real(c_double) :: lo(3), hi(3)
-    outside = .false.
-    if (n == 0) return
-    call check(ctx, sph_get_bbox(ctx, lo, hi), 'sph_get_bbox')
-    outside = any(abs(lo) > bounding_size) .or. any(abs(hi) > bounding_size)
-  end subroutine pull_positions_outside
 end module sph_hip_host

@@ -26,25 +26,30 @@ def test_host_builds_with_amdflang():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["sod1000_traj", "disc3000_traj"])
-def test_fortran_host_trajectory(tmp_path, name):
+@pytest.mark.parametrize("name,variant,nsteps", [("sod1000_traj", "sph", 5), ("disc3000_traj", "sph", 5),
+                                                 ("disc3000_traj", "full", 5), ("acc2000_traj", "full", 3)])
+def test_fortran_host_trajectory(tmp_path, name, variant, nsteps):
+    """variant 'full' = the host's default: simulate() as the reference runs it (gas self-gravity, accretion,
+    boundary cull); 'sph' leaves those three out"""
     g = load_golden(name)
     icf = tmp_path / "ic.txt"
     txtio.write_ic(str(icf), g["ic"])
     snap = tmp_path / "final.txt"
-    r = subprocess.run([_build(), str(icf), "5", str(snap)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    cmd = [_build(), str(icf), str(nsteps), str(snap)] + (["sph"] if variant == "sph" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Successfully read" in r.stdout
     dts = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("dt ")]
-    assert dts == list(g["sph_dt_seq"])            # identical dt decisions through the Fortran loop
+    assert dts == list(g[variant + "_dt_seq"])       # identical dt decisions through the Fortran loop
     gas, sinks = txtio.read_snapshot(str(snap))
-    p = "sph_s5_"
+    p = f"{variant}_s{nsteps}_"
+    assert gas.shape[0] == g[p + "x"].size             # accretion / cull followed by the host
     for col, f in enumerate("x y z vx vy vz u m alpha".split()):
-        ref = g[p + f]
-        assert rel_err(gas[:, col], ref) <= 1e-11, f
+        assert rel_err(gas[:, col], g[p + f]) <= 1e-11, f
     assert sinks.shape[0] == g[p + "sx"].size
     assert np.max(np.abs(sinks[:, 0] - g[p + "sx"])) <= 1e-11
     assert np.max(np.abs(sinks[:, 3] - g[p + "svx"])) <= 1e-11
+    assert np.max(np.abs(sinks[:, 7] - g[p + "sm"])) <= 1e-14
 
 
 @pytest.mark.gpu
