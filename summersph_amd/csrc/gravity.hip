@@ -74,6 +74,9 @@ struct TreeArrays {
     int32_t *slot;                      // leaf -> cell-sorted slot
     int32_t *lvl;                       // internal: octree level of the node's smallest box, or -1 (partial group)
     int32_t *rope, *leaf_rope;          // next node after this subtree in depth-first order
+    int4 *walkB;                        // internal: {first octree node / leaf below, rope, level, -} with partial
+                                        // (non-octree) binary nodes skipped on both pointers
+    int2 *leafB;                        // leaves: {rope (partial nodes skipped), cell-sorted slot}
 };
 
 __global__ __launch_bounds__(GB) void radix_tree(const uint64_t *__restrict__ k, int n, TreeArrays t) {
@@ -182,15 +185,17 @@ __global__ __launch_bounds__(GB) void node_finish(int n, TreeArrays t) {
     }
 }
 
-// [F]:129-146 (table in global memory: the walk touches it once per accepted node)
-__device__ __forceinline__ double grav_lookup(const double *__restrict__ gt, int nq, double dq, double r, double h) {
-    const double qi = r / h;
-    if (qi <= 2.0) {
-        const int k = min((int)(qi / dq), nq - 1);
-        const double a = (qi - k * dq) / dq;
-        return (1.0 - a) * gt[k] + a * gt[k + 1];
-    }
-    return 1.0;
+// The walk only ever TESTS octree nodes and leaves; partial binary nodes are opened unconditionally, so both
+// pointers of the walk records jump over them: eff(x) = x if x is a leaf or an octree node, else eff(left(x)).
+__device__ __forceinline__ int eff_node(const TreeArrays &t, int x) {
+    while (x != END && x >= 0 && t.lvl[x] < 0) x = t.left[x];
+    return x;
+}
+
+__global__ __launch_bounds__(GB) void node_walk_records(int n, TreeArrays t) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i < n - 1) t.walkB[i] = make_int4(eff_node(t, t.left[i]), eff_node(t, t.rope[i]), t.lvl[i], 0);
+    if (i < n) t.leafB[i] = make_int2(eff_node(t, t.leaf_rope[i]), t.slot[i]);
 }
 
 // the walk, [F]:264-290.  Writes a = 0 - sum (the forces kernels continue from there, [F]:824-827).
@@ -204,38 +209,47 @@ __global__ __launch_bounds__(GB) void grav_walk(int n, TreeArrays t, RootBox rb,
     if (orig[i] >= n_owned) return;
     const double4 p = drec[i];
     const double hp = hvar ? hvar[i] : hfix;
+    const double inv_hp = 1.0 / hp, inv_dq = 1.0 / dq, theta2 = theta * theta;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    // the root is an octree node by construction (level >= 0)
     int node = n >= 2 ? 0 : END;
     while (node != END) {
         double4 c;
         int next_open, next_skip;
-        bool leaf, partial = false;
+        bool leaf;
         double size = 0.0;
         if (node < 0) {
             const int j = ~node;
+            const int2 lb = t.leafB[j];
+            next_skip = lb.x; next_open = lb.x;
+            if (lb.y == i) { node = next_skip; continue; }           // own leaf: direction = 0, contributes nothing
             c = t.leafA[j];
             leaf = true;
-            next_skip = t.leaf_rope[j];
-            next_open = next_skip;
-            if (t.slot[j] == i) { node = next_skip; continue; }       // own leaf: direction = 0, contributes nothing
         } else {
+            const int4 wb = t.walkB[node];
             c = t.sum[node];
             leaf = false;
-            const int lv = t.lvl[node];
-            partial = lv < 0;
-            size = ldexp(rb.size, -max(lv, 0));
-            next_open = t.left[node];
-            next_skip = t.rope[node];
+            size = ldexp(rb.size, -wb.z);
+            next_open = wb.x; next_skip = wb.y;
         }
-        if (partial) { node = next_open; continue; }                  // not an octree node: the reference never tests it
         const double d0 = p.x - c.x, d1 = p.y - c.y, d2c = p.z - c.z;  // [F]:274
         const double d2 = (d0 * d0 + d1 * d1 + d2c * d2c) + soft2;    // [F]:275
-        const double dist = sqrt(d2);
-        if (leaf || (size / dist) < theta) {                          // [F]:278
-            if (c.w > 0.0 && dist > 0.0) {
-                const double W = grav_lookup(gt, nq, dq, dist, hp);   // [F]:280
-                const double f = G * c.w * W / (dist * dist * dist);  // [F]:281
-                a0 = a0 - f * d0; a1 = a1 - f * d1; a2 = a2 - f * d2c;
+        // [F]:278: size/dist < theta  <=>  size^2 < theta^2 d2 (all positive): opened nodes need neither the
+        // square root nor the division (the two forms can only disagree within an ulp of the threshold)
+        if (leaf || size * size < theta2 * d2) {
+            if (c.w > 0.0) {
+                double dist, rs;
+                fast_sqrt_rsqrt(d2, dist, rs);
+                const double qi = dist * inv_hp;
+                double W = 1.0;                                        // [F]:129-146: 1 beyond the softening support
+                if (qi <= 2.0) {
+                    const double tq = qi * inv_dq;
+                    const int k = min((int)tq, nq - 1);
+                    const double a = tq - (double)k;
+                    W = (1.0 - a) * gt[k] + a * gt[k + 1];
+                }
+                const double f = (G * c.w) * W * (rs * rs * rs);      // [F]:281: G M W / dist^3
+                a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
             }
             node = next_skip;
         } else {
@@ -269,6 +283,7 @@ static TreeArrays tree_arrays(sph_ctx *c) {
     t.left = c->g_left; t.right = c->g_right; t.parent = c->g_parent; t.leaf_parent = c->g_leaf_parent; t.prefix = c->g_prefix;
     t.flag = c->g_flag; t.sum = reinterpret_cast<double4 *>(c->g_sum); t.leafA = reinterpret_cast<double4 *>(c->g_leafA);
     t.slot = c->g_slot; t.lvl = c->g_lvl; t.rope = c->g_rope; t.leaf_rope = c->g_leaf_rope;
+    t.walkB = reinterpret_cast<int4 *>(c->g_walkB); t.leafB = reinterpret_cast<int2 *>(c->g_leafB);
     return t;
 }
 
@@ -298,6 +313,7 @@ int gravity_tree_build(sph_ctx *c) {
         node_sums<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
     }
     node_finish<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
+    node_walk_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
     GR_CHECK2(hipGetLastError());
     return SPH_OK;
 }

@@ -95,6 +95,7 @@ struct sph_ctx {
     int32_t *g_left = nullptr, *g_right = nullptr, *g_parent = nullptr, *g_leaf_parent = nullptr, *g_prefix = nullptr;
     int32_t *g_flag = nullptr, *g_slot = nullptr, *g_lvl = nullptr, *g_rope = nullptr, *g_leaf_rope = nullptr;
     double *g_sum = nullptr, *g_leafA = nullptr;     // 4 doubles per node / leaf
+    int32_t *g_walkB = nullptr, *g_leafB = nullptr;  // int4 per node, int2 per leaf: packed walk pointers
     double *grav_tab = nullptr;                      // softening table, [F]:81-101
 
     // grid
