@@ -238,6 +238,18 @@ def main():
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in vkt.items()}, "final_dt": vdt,
                 "target_BASELINE_md": 1.0e7}
             vctx.close()
+            # simulate() as the reference runs it: + Barnes-Hut gas self-gravity, accretion, boundary cull
+            fctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank,
+                                   capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+            fsteps = max(2, args.steps // 2)
+            fel, fdt = timed_run(fctx, torch, fsteps, 1)
+            fkt = {k: fctx.timing_get(k) for k in capi.KERNELS}
+            out["full_simulate"] = {
+                "workload": f"the headline disc with find_forces as the reference has it (Barnes-Hut gas self-gravity, "
+                            f"theta 0.5) and the end-of-step sink accretion + boundary cull",
+                "value": args.n * fsteps / fel, "unit": "particle-steps/s", "ms_per_step": fel / fsteps * 1e3, "steps": fsteps,
+                "kernel_ms_per_step": {k: v[0] / fsteps for k, v in fkt.items()}, "particles_left": fctx.n}
+            fctx.close()
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n, args.nngb)
         print(json.dumps(out), flush=True)
