@@ -121,6 +121,7 @@ typedef struct sph_stats {
     double  nlist_mean;     /* mean neighbour count (pairs inside 2h, self excluded)      */
     int64_t grid_builds, nlist_builds, density_passes, force_passes;
     int64_t device_bytes;   /* HBM held by the context                                    */
+    double  nlist_wave_mean;/* mean over wavefronts of the longest list in the wave = trips the pair kernels run */
 } sph_stats;
 
 /* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation
@@ -207,6 +208,40 @@ int sph_gather_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int64
                           const int64_t *d_ids, double *d_out);
 int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int64_t first, int64_t count,
                            const double *d_vals);
+/* ---- the same exchange kept on the device (no re-upload, no host reductions) ----------------
+ * sph_set_stream      run the context on the caller's HIP stream (e.g. torch's current stream; NULL =
+ *                     the default stream): calls that take device pointers then stop synchronising
+ *                     and are ordered with the caller's own work on that stream.
+ * sph_reserve         minimum slot capacity of the next sph_upload (room for ghosts).
+ * sph_owned_bbox      min xyz, max xyz of the owned particles at their current positions, to the host
+ *                     (lo_hi, synchronises) and/or to device memory (d_lo_hi).
+ * sph_select_boxes    for each of nbox boxes {lo xyz, hi xyz}: the owned particles inside, ascending
+ *                     original id; counts to the host; ids fetched with sph_selected_ids_dev.
+ * sph_replace_ghosts_dev  drop the current ghosts and append `count` new ones (d_state[f*count + k],
+ *                     f = x y z vx vy vz u m alpha); owned particles stay where they are, the next
+ *                     sph_density re-sorts everything.  SPH_ERR_NOMEM if the slots do not suffice.
+ * sph_set_dt / sph_get_dt, sph_kick_devdt / sph_drift_devdt: dt and t held on the device
+ *                     (sph_run's mechanism), so that a step needs no host round trip for them.
+ * sph_dt_candidate_dev    local dt candidate ([F]:845-851 over owned particles) kept on the device.
+ * sph_pack_partials_dev   d_out[0..3*64) = this GPU's partial sink accelerations (ax[64] ay[64]
+ *                     az[64]), d_out[192] = its dt candidate: SPH_PARTIALS doubles, to be
+ *                     all-gathered by the caller.
+ * sph_apply_partials_dev  sink accelerations = sum over the nranks gathered blocks (rank order);
+ *                     apply_dt != 0: t += dt, then [F]:855-858 with the minimum candidate.          */
+#define SPH_PARTIALS 193
+int sph_set_stream(sph_ctx *ctx, void *hip_stream);
+int sph_reserve(sph_ctx *ctx, int64_t n_slots);
+int sph_owned_bbox(sph_ctx *ctx, double *lo_hi, double *d_lo_hi);
+int sph_select_boxes(sph_ctx *ctx, int32_t nbox, const double *boxes, int64_t *counts);
+int sph_selected_ids_dev(sph_ctx *ctx, int32_t box, int64_t count, int64_t *d_ids);
+int sph_replace_ghosts_dev(sph_ctx *ctx, int64_t count, const double *d_state);
+int sph_set_dt(sph_ctx *ctx, double dt, double t);
+int sph_get_dt(sph_ctx *ctx, double *dt, double *t);
+int sph_kick_devdt(sph_ctx *ctx);
+int sph_drift_devdt(sph_ctx *ctx);
+int sph_dt_candidate_dev(sph_ctx *ctx);
+int sph_pack_partials_dev(sph_ctx *ctx, double *d_out);
+int sph_apply_partials_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt);
 /* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */
 int sph_refresh_eos(sph_ctx *ctx);
 /* the local part of get_next_timestep ([F]:845-851): min over OWNED particles * dt_scale;

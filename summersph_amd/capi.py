@@ -33,6 +33,9 @@ SYMBOLS = [
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
+    "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
+    "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_pack_partials_dev",
+    "sph_apply_partials_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
@@ -51,7 +54,7 @@ class Stats(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_cells", C.c_int64), ("grid_dim", C.c_int32 * 3),
                 ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("nlist_mean", C.c_double),
                 ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
-                ("force_passes", C.c_int64), ("device_bytes", C.c_int64)]
+                ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double)]
 
 
 class SphError(RuntimeError):
@@ -116,6 +119,18 @@ def load():
     lib.sph_refresh_eos.argtypes = [C.c_void_p]
     lib.sph_dt_candidate.argtypes = [C.c_void_p, _D]
     lib.sph_set_sink_accel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sph_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sph_reserve.argtypes = [C.c_void_p, C.c_int64]
+    lib.sph_owned_bbox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sph_select_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.sph_selected_ids_dev.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    lib.sph_replace_ghosts_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.sph_set_dt.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.sph_get_dt.argtypes = [C.c_void_p, _D, _D]
+    for f in ("sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev"):
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.sph_pack_partials_dev.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sph_apply_partials_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
     _lib = lib
@@ -261,6 +276,57 @@ class Context:
     def scatter_fields_dev(self, names, first: int, count: int, vals_ptr: int):
         f = (C.c_int32 * len(names))(*[FIELDS.index(n) for n in names])
         self._ck(self.lib.sph_scatter_fields_dev(self._h, len(names), f, int(first), int(count), C.c_void_p(int(vals_ptr))))
+
+    # ---- the device-resident multi-GPU exchange (include/summersph.h, "kept on the device") ----
+    def set_stream(self, stream_handle: int):
+        self._ck(self.lib.sph_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def reserve(self, n_slots: int):
+        self._ck(self.lib.sph_reserve(self._h, n_slots))
+
+    def owned_bbox(self, dev_ptr: int = 0) -> np.ndarray | None:
+        """dev_ptr == 0: returns min xyz, max xyz on the host; else writes them to device memory (no sync)"""
+        if dev_ptr:
+            self._ck(self.lib.sph_owned_bbox(self._h, None, C.c_void_p(dev_ptr)))
+            return None
+        out = np.empty(6)
+        self._ck(self.lib.sph_owned_bbox(self._h, out.ctypes.data, None))
+        return out
+
+    def select_boxes(self, boxes: np.ndarray) -> np.ndarray:
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        counts = np.zeros(boxes.shape[0], dtype=np.int64)
+        self._ck(self.lib.sph_select_boxes(self._h, boxes.shape[0], boxes.ctypes.data, counts.ctypes.data))
+        return counts
+
+    def selected_ids_dev(self, box: int, count: int, dev_ptr: int):
+        self._ck(self.lib.sph_selected_ids_dev(self._h, box, count, C.c_void_p(dev_ptr)))
+
+    def replace_ghosts_dev(self, count: int, dev_ptr: int):
+        self._ck(self.lib.sph_replace_ghosts_dev(self._h, count, C.c_void_p(dev_ptr)))
+
+    def set_dt(self, dt: float, t: float = 0.0):
+        self._ck(self.lib.sph_set_dt(self._h, dt, t))
+
+    def get_dt(self):
+        dt, t = C.c_double(0.0), C.c_double(0.0)
+        self._ck(self.lib.sph_get_dt(self._h, C.byref(dt), C.byref(t)))
+        return dt.value, t.value
+
+    def kick_devdt(self):
+        self._ck(self.lib.sph_kick_devdt(self._h))
+
+    def drift_devdt(self):
+        self._ck(self.lib.sph_drift_devdt(self._h))
+
+    def dt_candidate_dev(self):
+        self._ck(self.lib.sph_dt_candidate_dev(self._h))
+
+    def pack_partials_dev(self, dev_ptr: int):
+        self._ck(self.lib.sph_pack_partials_dev(self._h, C.c_void_p(dev_ptr)))
+
+    def apply_partials_dev(self, dev_ptr: int, nranks: int, stride: int, apply_dt: bool):
+        self._ck(self.lib.sph_apply_partials_dev(self._h, C.c_void_p(dev_ptr), nranks, stride, 1 if apply_dt else 0))
 
     def refresh_eos(self):
         self._ck(self.lib.sph_refresh_eos(self._h))

@@ -229,7 +229,7 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(hipGetLastError());
     for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
     if (c->variable) std::swap(c->f[SPH_F_H], c->f_alt[9]);
-    c->n = n_new;
+    c->n = n_new; c->n_slots = n_new; c->dead_below = 0;
     c->n_owned = n_new;
     AC_CHECK(launch_iota(c, c->orig, n_new));
     AC_CHECK(launch_iota(c, c->inv, n_new));

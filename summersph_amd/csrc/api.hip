@@ -43,6 +43,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max);
+    ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
     ctx_free(c, c->g_left); ctx_free(c, c->g_right); ctx_free(c, c->g_parent); ctx_free(c, c->g_leaf_parent);
@@ -53,9 +54,9 @@ void free_particle_arrays(sph_ctx *c) {
 }
 
 int ensure_capacity(sph_ctx *c, int64_t n) {
-    if (n <= c->cap) return SPH_OK;
+    if (std::max(n, c->reserve) <= c->cap) return SPH_OK;
     free_particle_arrays(c);
-    const int64_t cap = n + n / 16 + 64;
+    const int64_t cap = std::max<int64_t>(n + n / 16 + 64, c->reserve);
     for (auto &p : c->f) API_TRY(ctx_alloc(c, &p, (size_t)cap, "state"));
     for (auto &p : c->f_alt) API_TRY(ctx_alloc(c, &p, (size_t)cap, "state (alt)"));
     API_TRY(ctx_alloc(c, &c->orig, (size_t)cap, "ids"));
@@ -386,9 +387,9 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     int st = SPH_OK;
     auto fail = [&](int s) { sph_ctx_destroy(c); return s; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
-    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
-    std::memset(c->h_pinned, 0, 64 * sizeof(double));
-    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 8, "bbox")) != SPH_OK) return fail(st);
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 256 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
+    std::memset(c->h_pinned, 0, 256 * sizeof(double));
+    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 16, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
@@ -433,7 +434,8 @@ int sph_ctx_destroy(sph_ctx *c) {
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    ctx_free(c, c->sel_count); ctx_free_ptr(c, c->sel_tmp);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
 }
@@ -447,7 +449,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
         if (n > 0 && !src[k]) { c->err = "sph_upload: null array"; return SPH_ERR_ARG; }
     DeviceGuard g(c->device);
     API_TRY(ensure_capacity(c, n));
-    c->n = n;
+    c->n = n; c->n_slots = n; c->dead_below = 0;
     c->n_owned = n;
     for (int k = 0; k < 9; k++) {
         if (n == 0) break;
@@ -565,14 +567,20 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
     o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
     o->density_passes = c->density_passes; o->force_passes = c->force_passes;
     o->device_bytes = c->device_bytes;
-    if (c->n > 0 && c->grid_valid) {
+    if (c->n > 0 && c->nlist_builds > 0 && c->ncount && c->n <= c->cap) {      // counts of the last build
         DeviceGuard g(c->device);
         std::vector<int32_t> cnt((size_t)c->n);
         API_HIP(hipStreamSynchronize(c->stream));
         API_HIP(hipMemcpy(cnt.data(), c->ncount, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        double s = 0.0;
+        double s = 0.0, sw = 0.0;
         for (int32_t v : cnt) s += v;
         o->nlist_mean = s / (double)c->n;
+        for (size_t w = 0; w < cnt.size(); w += 64) {
+            int32_t m = 0;
+            for (size_t k = w; k < std::min(cnt.size(), w + 64); k++) m = std::max(m, cnt[k]);
+            sw += m;
+        }
+        o->nlist_wave_mean = sw / (double)((cnt.size() + 63) / 64);
     }
     return SPH_OK;
 }
@@ -657,7 +665,7 @@ int sph_gather_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_t
     if (!fields_ok(c, nf, fields, true)) { c->err = "sph_gather_fields_dev: bad or stale field"; return SPH_ERR_ARG; }
     DeviceGuard g(c->device);
     API_HIP(launch_gather_fields(c, nf, fields, d_ids, count, d_out));
-    API_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
 
@@ -702,6 +710,98 @@ int sph_set_sink_accel(sph_ctx *c, int32_t ns, const double *sax, const double *
     const double *src[3] = {sax, say, saz};
     for (int k = 0; k < 3; k++)
         if (ns > 0) API_HIP(hipMemcpy(c->sink + (size_t)(7 + k) * MAX_SINKS, src[k], (size_t)ns * sizeof(double), hipMemcpyHostToDevice));
+    return SPH_OK;
+}
+
+int sph_set_stream(sph_ctx *c, void *stream) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+    c->stream = reinterpret_cast<hipStream_t>(stream);      // NULL = the device's default stream
+    c->own_stream = false;
+    return SPH_OK;
+}
+
+int sph_reserve(sph_ctx *c, int64_t n_slots) {
+    if (!c || n_slots < 0) return SPH_ERR_ARG;
+    c->reserve = n_slots;
+    return SPH_OK;
+}
+
+int sph_owned_bbox(sph_ctx *c, double *lo_hi, double *d_lo_hi) {
+    if (!c || (!lo_hi && !d_lo_hi)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return owned_bbox(c, d_lo_hi, lo_hi);
+}
+
+int sph_select_boxes(sph_ctx *c, int32_t nbox, const double *boxes, int64_t *counts) {
+    if (!c || nbox < 0 || nbox > MAX_SEL_BOXES || (nbox > 0 && (!boxes || !counts))) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    c->sel_boxes = 0;
+    API_TRY(domain_select_boxes(c, nbox, boxes, counts));
+    c->sel_boxes = nbox;
+    for (int b = 0; b < nbox; b++) c->sel_counts[b] = counts[b];
+    return SPH_OK;
+}
+
+int sph_selected_ids_dev(sph_ctx *c, int32_t box, int64_t count, int64_t *d_ids) {
+    if (!c || box < 0 || box >= c->sel_boxes || count != c->sel_counts[box] || (count > 0 && !d_ids)) return SPH_ERR_ARG;
+    if (count == 0) return SPH_OK;
+    DeviceGuard g(c->device);
+    API_HIP(hipMemcpyAsync(d_ids, c->sel_ids + (size_t)box * c->n_owned, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_replace_ghosts_dev(sph_ctx *c, int64_t count, const double *d_state) {
+    if (!c || count < 0 || (count > 0 && !d_state)) return SPH_ERR_ARG;
+    if (c->variable) { c->err = "sph_replace_ghosts_dev: fixed-h contexts only"; return SPH_ERR_STATE; }
+    if (c->dead_below > 0) { c->err = "sph_replace_ghosts_dev: a ghost swap is already pending (call sph_density)"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    API_TRY(domain_replace_ghosts(c, count, d_state));
+    if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
+    return SPH_OK;
+}
+
+int sph_set_dt(sph_ctx *c, double dt, double t) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return put_dt(c, dt, t);
+}
+
+int sph_get_dt(sph_ctx *c, double *dt, double *t) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return get_dt(c, dt, t);
+}
+
+int sph_kick_devdt(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_kick(c, 0.0, true); }
+int sph_drift_devdt(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_drift(c, 0.0, true); }
+
+int sph_dt_candidate_dev(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    if (!c->rates_valid) { c->err = "sph_dt_candidate_dev: rates are stale"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    Timed t(c, SPH_K_DT);
+    API_HIP(launch_dt_partial_only(c));
+    return SPH_OK;
+}
+
+int sph_pack_partials_dev(sph_ctx *c, double *d_out) {
+    if (!c || !d_out) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(launch_pack_partials(c, d_out));
+    if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_apply_partials_dev(sph_ctx *c, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt) {
+    if (!c || !d_all || nranks < 1 || stride < SPH_PARTIALS) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(launch_apply_partials(c, d_all, nranks, stride, apply_dt != 0));
     return SPH_OK;
 }
 

@@ -38,13 +38,17 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // partial[b*6 + {0..2}] = min x,y,z ; {3..5} = max x,y,z over block b's grid-stride share
+// mode 0: every slot except replaced ghosts (slot < dead_below with original id >= n_owned); mode 1: owned only
 __global__ __launch_bounds__(BB_BLOCK) void bbox_partial(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ z, int64_t n,
-                                                         double *__restrict__ partial, int32_t *__restrict__ flags) {
+                                                         double *__restrict__ partial, int32_t *__restrict__ flags,
+                                                         const int32_t *__restrict__ orig, int32_t n_owned,
+                                                         int64_t dead_below, int owned_only) {
     __shared__ double sm[6][BB_BLOCK / WAVE];
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * BB_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BB_BLOCK) {
+        if ((owned_only || i < dead_below) && orig[i] >= n_owned) continue;
         double v[3] = {x[i], y[i], z[i]};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -93,13 +97,16 @@ __device__ __forceinline__ uint32_t cell_key(const GridDesc &g, double px, doubl
     return ((uint32_t)cc[2] * (uint32_t)g.dim[g.s[1]] + (uint32_t)cc[1]) * (uint32_t)g.dim[g.s[0]] + (uint32_t)cc[0];
 }
 
+// replaced ghosts (slot < dead_below, original id >= n_owned) get the key ncells: they sort behind every cell
 __global__ __launch_bounds__(256) void cell_keys(GridDesc g, const double *__restrict__ x, const double *__restrict__ y,
                                                  const double *__restrict__ z, int64_t n, uint32_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ vals) {
+                                                 uint32_t *__restrict__ vals, const int32_t *__restrict__ orig,
+                                                 int32_t n_owned, int64_t dead_below) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int cc[3];
-    keys[i] = cell_key(g, x[i], y[i], z[i], cc);
+    const bool dead = i < dead_below && orig[i] >= n_owned;
+    keys[i] = dead ? (uint32_t)g.ncells : cell_key(g, x[i], y[i], z[i], cc);
     vals[i] = (uint32_t)i;
 }
 
@@ -255,15 +262,38 @@ hipError_t launch_unpermute(sph_ctx *c, const double *src_sorted, double *dst_or
         }                                                                   \
     } while (0)
 
-int grid_rebuild(sph_ctx *c) {
-    const int64_t n = c->n;
+// bounding box of the owned particles at their current positions -> d_out6 (device) and/or h_out6 (host, synchronises)
+int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6) {
     hipStream_t st = c->stream;
-    if (n == 0) { c->grid_valid = true; return SPH_OK; }
+    const int64_t ns = c->n_slots;
+    int nb = (int)std::min<int64_t>((ns + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
+    if (nb < 1) nb = 1;
+    double *res = c->bbox_part + (size_t)BB_MAX_BLOCKS * 6 + 8;
+    bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->bbox_part, c->d_flags + 2,
+                                                      c->orig, (int32_t)c->n_owned, 0, 1);
+    bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, res);
+    GR_CHECK(hipGetLastError());
+    if (d_out6) GR_CHECK(hipMemcpyAsync(d_out6, res, 6 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (h_out6) {
+        GR_CHECK(hipMemcpyAsync(c->h_pinned + 48, res, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+        GR_CHECK(hipStreamSynchronize(st));
+        for (int a = 0; a < 6; a++) h_out6[a] = c->h_pinned[48 + a];
+    }
+    return SPH_OK;
+}
+
+int grid_rebuild(sph_ctx *c) {
+    const int64_t n = c->n;                 // live particles after the build
+    const int64_t ns = c->n_slots;          // occupied slots before it (> n while a ghost swap is pending)
+    const bool swap = c->dead_below > 0;
+    hipStream_t st = c->stream;
+    if (ns == 0) { c->grid_valid = true; return SPH_OK; }
 
     // ---- bounding box ---------------------------------------------------------------
-    int nb = (int)std::min<int64_t>((n + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
+    int nb = (int)std::min<int64_t>((ns + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
     GR_CHECK(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 2, st));
-    bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], n, c->bbox_part, c->d_flags);
+    bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->bbox_part, c->d_flags,
+                                                      c->orig, (int32_t)c->n_owned, c->dead_below, 0);
     bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
     GR_CHECK(hipGetLastError());
     GR_CHECK(hipMemcpyAsync(c->h_pinned, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -315,13 +345,15 @@ int grid_rebuild(sph_ctx *c) {
     }
 
     // ---- keys, sort, cell table ---------------------------------------------------------
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    cell_keys<<<dim3(gb), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], n, c->keys, c->vals);
+    const unsigned gb = (unsigned)((std::max<int64_t>(n, 1) + 255) / 256);
+    cell_keys<<<dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->keys,
+                                                                        c->vals, c->orig, (int32_t)c->n_owned, c->dead_below);
     GR_CHECK(hipGetLastError());
     unsigned bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) < g.ncells) bits++;
+    while (bits < 32 && ((int64_t)1 << bits) < g.ncells + (swap ? 1 : 0)) bits++;
     size_t tmp = c->sort_tmp_bytes;
-    GR_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->keys, c->keys_alt, c->vals, c->vals_alt, (size_t)n, 0u, bits, st));
+    GR_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->keys, c->keys_alt, c->vals, c->vals_alt, (size_t)ns, 0u, bits, st));
+    c->n_slots = n; c->dead_below = 0;     // the replaced ghosts sorted behind the n live entries and are dropped here
     cell_table<<<dim3((unsigned)((g.ncells + 1 + 255) / 256)), dim3(256), 0, st>>>(c->keys_alt, n, g.ncells, c->cell_start);
     GR_CHECK(hipGetLastError());
 

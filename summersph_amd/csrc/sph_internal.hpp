@@ -15,6 +15,8 @@ namespace sph {
 constexpr int WAVE = 64;           // CDNA wavefront
 constexpr int FREC = 12;           // doubles per force gather record
 constexpr int MAX_SINKS = 64;      // sinks handled by the in-kernel loops
+constexpr int MAX_SEL_BOXES = 64;  // boxes per sph_select_boxes call (multi-GPU ghost selection)
+struct FieldPtrs9 { double *p[9]; };
 
 // Uniform cell grid over the particles' bounding box.  Axes are permuted so that
 // axis s[0] (the one with the fewest cells) varies fastest in the cell key: for a disc
@@ -62,6 +64,15 @@ struct sph_ctx {
     int64_t n_owned = 0;  // original ids [0, n_owned) are this GPU's particles; [n_owned, n) are ghost
                           // copies of other GPUs' particles: neighbours only, never targets
     int64_t cap = 0;      // allocated particle slots
+    int64_t reserve = 0;  // minimum capacity requested by sph_reserve (room for ghost swaps)
+    // multi-GPU ghost swap (domain.hip): between sph_replace_ghosts_dev and the next grid build the arrays hold
+    // n_slots > n entries; slots below dead_below whose original id is >= n_owned are the replaced ghosts
+    int64_t n_slots = 0, dead_below = 0;
+    int64_t *sel_ids = nullptr; size_t sel_cap = 0;      // box selection results, nbox x n_owned
+    int64_t *sel_count = nullptr;
+    void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;
+    int32_t sel_boxes = 0; int64_t sel_counts[64] = {};  // last sph_select_boxes
+    bool own_stream = true;                              // false: the caller's stream (sph_set_stream), *_dev calls do not synchronise
 
     // cell-sorted struct-of-arrays state + derived + rates (SPH_F_* order)
     double *f[SPH_F_COUNT] = {};
@@ -179,6 +190,12 @@ hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_
 hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out);
 hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals);
 hipError_t launch_dt_partial_only(sph_ctx *c);
+// multi-GPU building blocks (domain.hip, grid.hip)
+int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6);      // h_out6 != nullptr: synchronises
+int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts);
+int domain_replace_ghosts(sph_ctx *c, int64_t count, const double *d_vals);
+hipError_t launch_pack_partials(sph_ctx *c, double *d_out);
+hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, int stride, bool apply_dt);
 // LDS-tiled fixed-h kernels (tiled.hip; default)
 int nlist_build_tiled(sph_ctx *c);
 hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);

@@ -2,48 +2,64 @@
 
 Interactions are short range (2h), so the path shards by space: every rank owns the particles of one
 slab along x (slab edges = particle-count quantiles) and keeps GHOST copies of the other ranks'
-particles that lie within 2h of its own particles' bounding box.  Per force evaluation:
+particles that lie within 2h of its own particles' bounding box.  The owned particles never leave
+the GPU context; per step (= the reference's loop body, [F]:889-916) the ranks exchange only:
 
-  positions changed (after a drift)                    positions unchanged (start of the next step)
-  1. migrate particles that left their slab            1. refresh ghost v, u, alpha (they were kicked
-  2. all-gather the ranks' bounding boxes                 by their owners)
-  3. send owned particles inside bbox_q (+2h) to q     2. density of owned particles again (as the
-  4. upload owned + ghosts, density of owned              reference does), EOS of everything
-  5. send rho of the same particles -> ghost rho       3. forces
-  6. EOS of ghosts, forces of owned
-  then: sink accelerations summed over ranks (all-reduce), and at the end of a step the dt
-  candidate is min-reduced and the reference's dt rule ([F]:855-858) is applied on every rank.
+  start of step (positions as at the end of the last step)
+    1. point-to-point: v, u, alpha of the ghosts (their owners kicked them)
+       density + EOS + forces
+    2. all-gather [193 doubles/rank]: partial sink accelerations, and the dt candidate left by the
+       previous step -> summed / min-reduced on the device in rank order, dt rule [F]:855-858
+  kick, drift
+  end of step (positions changed)
+    3. all-gather: bounding boxes of the owned particles          (host: which peers overlap)
+    4. all-gather: how many particles each rank sends to each peer (host: message sizes)
+    5. point-to-point: the 9 state fields of the particles inside (peer box + 2h); they replace the
+       ghost slots of the context (sph_replace_ghosts_dev)
+       density of the owned particles
+    6. point-to-point: rho of the same particles -> ghost rho; EOS, forces
+    7. all-gather [193 doubles/rank]: partial sink accelerations
+  kick; the local dt candidate stays on the device until 2. of the next step.
+
+Every `migrate_every` steps the particles that left their slab change owner first (the ghost
+selection uses bounding boxes, not slab edges, so ownership only matters for load balance).
 
 torch.distributed carries every exchange: backend "nccl" (= RCCL over xGMI; every pair of GPUs has
-a direct link, so the point-to-point halo messages of different pairs do not share links) on a GPU
-node, "gloo" for the CPU tests.  The arithmetic is done by a *backend object*: `HipBackend` (the
-C ABI, device memory) in production; tests plug in an oracle-based backend to exercise this
-orchestration on CPUs.  Nothing in this module computes physics.
+a direct link, so the halo messages of different pairs do not share links) on a GPU node, "gloo"
+for the CPU tests.  The arithmetic is done by a *backend object*: `HipBackend` (the C ABI, device
+memory, running on torch's current stream so that no host synchronisation separates the library's
+kernels from torch's collectives) in production; tests plug in an oracle-based backend to exercise
+this orchestration on CPUs.  Nothing in this module computes physics.
 """
 from __future__ import annotations
+
+import contextlib
+import time
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
+PARTIALS = 193          # SPH_PARTIALS: ax[64] ay[64] az[64] of the sinks + the dt candidate
 
 
 class HipBackend:
     """The C-ABI context as seen by the orchestrator.  Tensors are float64 on `device`.
 
-    The library runs on its own HIP stream, torch on its current stream: every hand-over of a torch
-    buffer to the library is preceded by torch.cuda.synchronize (torch's caching allocator may recycle
-    memory that queued torch kernels still read), and every library call that fills a buffer
-    synchronises its stream before returning."""
+    The context runs on torch's current stream (sph_set_stream): the library's kernels, torch's own
+    kernels and the waits torch inserts around its collectives are all ordered on that one stream,
+    so buffers are handed back and forth without host synchronisation."""
 
     def __init__(self, device_index: int = 0, **param_overrides):
         from . import capi
         self.capi = capi
         self.ctx = capi.Context(device=device_index, **param_overrides)
         self.device = torch.device("cuda", device_index)
-        self.n = 0
+        with torch.cuda.device(self.device):
+            self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.n_owned = 0
+        self._reserved = 0
 
     @property
     def params(self):
@@ -52,28 +68,46 @@ class HipBackend:
     def set_rank(self, rank, nranks):
         self.ctx.set_rank(rank, nranks)
 
-    def upload(self, state: torch.Tensor, n_owned: int):
-        """state: [9, n] (rows in STATE order), owned particles first, then ghosts"""
+    def upload(self, state: torch.Tensor):
+        """state: [9, n] (rows in STATE order): this rank's owned particles; ghosts come later"""
         state = state.contiguous()
-        self.n = int(state.shape[1])
-        self.n_owned = int(n_owned)
-        torch.cuda.synchronize(self.device)
-        self.ctx.upload_dev(self.n, [state[k].data_ptr() for k in range(9)])
-        self.ctx.set_owned(self.n_owned)
+        n = int(state.shape[1])
+        self.n_owned = n
+        if n + n // 8 + 32768 > self._reserved:         # room for the ghost swaps; grows rarely (a re-allocation)
+            self._reserved = n + n // 4 + 65536
+            self.ctx.reserve(self._reserved)
+        self.ctx.upload_dev(n, [state[k].data_ptr() for k in range(9)])
+
+    def owned_bbox(self) -> torch.Tensor:
+        out = torch.empty(6, dtype=torch.float64, device=self.device)
+        self.ctx.owned_bbox(out.data_ptr())
+        return out
+
+    def select_boxes(self, boxes: np.ndarray) -> list:
+        """per box {lo xyz, hi xyz}: original ids (ascending, int64 tensor) of the owned particles inside"""
+        counts = self.ctx.select_boxes(boxes)
+        out = []
+        for b, cnt in enumerate(counts):
+            ids = torch.empty(int(cnt), dtype=torch.int64, device=self.device)
+            self.ctx.selected_ids_dev(b, int(cnt), ids.data_ptr())
+            out.append(ids)
+        return out
+
+    def replace_ghosts(self, state: torch.Tensor):
+        state = state.contiguous()
+        self.ctx.replace_ghosts_dev(int(state.shape[1]), state.data_ptr())
 
     def gather(self, names, ids: torch.Tensor | None = None, count: int | None = None) -> torch.Tensor:
         """[len(names), count] values of the particles with original ids `ids` (None: 0..count-1)"""
         count = int(ids.numel()) if ids is not None else int(count)
         out = torch.empty((len(names), count), dtype=torch.float64, device=self.device)
         if count:
-            torch.cuda.synchronize(self.device)
             self.ctx.gather_fields_dev(names, count, ids.data_ptr() if ids is not None else 0, out.data_ptr())
         return out
 
     def scatter(self, names, first: int, vals: torch.Tensor):
         vals = vals.contiguous()
         if vals.numel():
-            torch.cuda.synchronize(self.device)
             self.ctx.scatter_fields_dev(names, first, vals.shape[1], vals.data_ptr())
 
     def set_sinks(self, sinks):
@@ -81,9 +115,6 @@ class HipBackend:
 
     def get_sinks(self):
         return self.ctx.get_sinks()
-
-    def set_sink_accel(self, ax, ay, az):
-        self.ctx.set_sink_accel(ax, ay, az)
 
     def density(self):
         self.ctx.density()
@@ -94,14 +125,29 @@ class HipBackend:
     def forces(self):
         self.ctx.forces()
 
-    def kick(self, dt):
-        self.ctx.kick(dt)
+    def set_dt(self, dt, t):
+        self.ctx.set_dt(dt, t)
 
-    def drift(self, dt):
-        self.ctx.drift(dt)
+    def get_dt(self):
+        return self.ctx.get_dt()
 
-    def dt_candidate(self):
-        return self.ctx.dt_candidate()
+    def kick(self):
+        self.ctx.kick_devdt()
+
+    def drift(self):
+        self.ctx.drift_devdt()
+
+    def dt_candidate_local(self):
+        self.ctx.dt_candidate_dev()
+
+    def pack_partials(self) -> torch.Tensor:
+        out = torch.empty(PARTIALS, dtype=torch.float64, device=self.device)
+        self.ctx.pack_partials_dev(out.data_ptr())
+        return out
+
+    def apply_partials(self, allp: torch.Tensor, apply_dt: bool):
+        allp = allp.contiguous()
+        self.ctx.apply_partials_dev(allp.data_ptr(), int(allp.shape[0]), int(allp.shape[1]), apply_dt)
 
     def synchronize(self):
         self.ctx.synchronize()
@@ -120,7 +166,7 @@ class DistSim:
     arrays, STATE keys, optional 'gid'); `bounds` are the interior slab edges shared by all ranks."""
 
     def __init__(self, backend, gas: dict, sinks: dict, bounds: np.ndarray, h: float | None = None,
-                 group=None, comm_device=None, migrate: bool = True):
+                 group=None, comm_device=None, migrate: bool = True, migrate_every: int = 8):
         self.be = backend
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -130,27 +176,45 @@ class DistSim:
         self.h = float(h if h is not None else backend.params.h)
         self.bounds = torch.as_tensor(np.asarray(bounds, dtype=np.float64), device=self.dev)
         self.migrate = migrate
+        self.migrate_every = max(1, int(migrate_every))
         backend.set_rank(self.rank, self.P)
         n = int(np.asarray(gas["x"]).size)
         rows = [np.ascontiguousarray(gas[k] if k in gas and gas[k] is not None else np.zeros(n), dtype=np.float64) for k in STATE]
-        self.owned = torch.as_tensor(np.stack(rows), device=self.dev)            # [9, n_owned]
+        self.owned = torch.as_tensor(np.stack(rows), device=self.dev)            # [9, n_owned]; stale once in_backend
         gid = gas.get("gid")
         self.gid = torch.as_tensor(np.asarray(gid if gid is not None else np.arange(n), dtype=np.int64), device=self.dev)
         self.n_owned = n
-        self.sinks = {k: np.array(v, dtype=np.float64, copy=True) for k, v in sinks.items()}
-        backend.set_sinks(self.sinks)
-        self.pos_dirty = True     # ghosts (and the backend's arrays) do not match the owned positions
+        backend.set_sinks({k: np.array(v, dtype=np.float64, copy=True) for k, v in sinks.items()})
+        self.pos_dirty = True     # ghosts do not match the owned positions
         self.vel_dirty = False    # ghost v, u, alpha are older than their owners'
-        self.in_backend = False   # the current owned state lives in the backend (self.owned is stale)
+        self.in_backend = False   # the owned particles live in the backend (self.owned is stale)
+        self.dt_pending = False   # a local dt candidate waits for the next reduction
+        self.since_migrate = 0
         self.send_idx = [None] * self.P      # per peer: original ids of my particles it holds as ghosts
         self.ghost_first = [0] * self.P      # per peer: first original id of its ghosts in my context
         self.ghost_count = [0] * self.P
         self.t = 0.0
-        self.stats = {"ghosts": 0, "migrated": 0, "exchanges": 0}
+        self.stats = {"ghosts": 0, "migrated": 0, "exchanges": 0, "migrations": 0}
+        self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
+        self.phase_s = {}
+        self._gather_into = True  # all_gather_into_tensor until the backend refuses it
+        if self.P > 1 and self.migrate:
+            self.prime()
+
+    @contextlib.contextmanager
+    def _phase(self, name):
+        if not self.profile:
+            yield
+            return
+        self.be.synchronize()
+        t0 = time.perf_counter()
+        yield
+        self.be.synchronize()
+        self.phase_s[name] = self.phase_s.get(name, 0.0) + time.perf_counter() - t0
 
     # ---- communication helpers ------------------------------------------------------------------
-    def _p2p(self, send: list, recv_counts: list, width: int):
-        """send[q]: tensor [width, n_q] (or None) for peer q; returns recv[q]: tensor [width, recv_counts[q]]"""
+    def _p2p_start(self, send: list, recv_counts: list, width: int):
+        """send[q]: tensor [width, n_q] (or None) for peer q; posts the sends and receives and returns a handle"""
         recv = [None] * self.P
         ops, keep = [], []
         for q in range(self.P):
@@ -164,24 +228,45 @@ class DistSim:
                 r = torch.empty((width, recv_counts[q]), dtype=torch.float64, device=self.comm_dev)
                 recv[q] = r
                 ops.append(dist.P2POp(dist.irecv, r, q, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        works = dist.batch_isend_irecv(ops) if ops else []
         self.stats["exchanges"] += 1
+        return works, recv, keep
+
+    def _p2p_finish(self, handle):
+        """waits for a _p2p_start; returns recv[q]: tensor [width, recv_counts[q]] on the compute device (or None)"""
+        works, recv, _keep = handle
+        for w in works:
+            w.wait()
         return [r.to(self.dev) if r is not None else None for r in recv]
 
-    def _all_gather_rows(self, row: torch.Tensor) -> torch.Tensor:
-        """every rank contributes one 1-D tensor of equal length -> [P, len] on the host"""
-        mine = row.to(self.comm_dev).contiguous()
-        out = [torch.empty_like(mine) for _ in range(self.P)]
-        dist.all_gather(out, mine, group=self.group)
-        return torch.stack(out).cpu()
+    def _p2p(self, send: list, recv_counts: list, width: int):
+        return self._p2p_finish(self._p2p_start(send, recv_counts, width))
 
-    def _allreduce(self, vals, op):
-        t = torch.tensor(vals, dtype=torch.float64, device=self.comm_dev)
-        if self.P > 1:
-            dist.all_reduce(t, op=op, group=self.group)
-        return t.cpu().numpy()
+    def prime(self):
+        """first use of a torch kernel loads its code object (tens of ms): do that for the ops of the rare migration
+        path now instead of in the middle of a run"""
+        x = torch.linspace(-1.0, 1.0, 16, dtype=torch.float64, device=self.dev)
+        b = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        dest = torch.bucketize(x, b, right=True)
+        torch.bincount(dest, minlength=2)
+        pay = torch.cat([x[None, :].repeat(9, 1), torch.arange(16, device=self.dev).to(torch.float64)[None, :]])
+        part = torch.cat([pay[:, dest == 0], pay[:, dest == 1]], dim=1)
+        part[:9].contiguous(); part[9].to(torch.int64)
+
+    def _all_gather(self, row: torch.Tensor) -> torch.Tensor:
+        """every rank contributes one 1-D tensor of equal length -> [P, len] on the communication device"""
+        mine = row.to(self.comm_dev).contiguous()
+        if self.P == 1:
+            return mine[None, :]
+        out = torch.empty((self.P, mine.numel()), dtype=mine.dtype, device=self.comm_dev)
+        if self._gather_into:
+            try:
+                dist.all_gather_into_tensor(out.view(-1), mine, group=self.group)
+                return out
+            except (RuntimeError, NotImplementedError):
+                self._gather_into = False
+        dist.all_gather(list(out.unbind(0)), mine, group=self.group)
+        return out
 
     # ---- domain bookkeeping -----------------------------------------------------------------------
     def _pull_owned(self):
@@ -190,13 +275,15 @@ class DistSim:
         self.in_backend = False
 
     def _migrate(self):
+        """particles that left their slab change owner (host-sized messages; only every migrate_every steps)"""
         x = self.owned[0]
         dest = torch.bucketize(x, self.bounds, right=True)
         counts = torch.bincount(dest, minlength=self.P)
-        cm = self._all_gather_rows(counts)                      # [P, P], row = sender, host
+        cm = self._all_gather(counts).cpu()                       # [P, P], row = sender
         mine_out = cm[self.rank].clone(); mine_out[self.rank] = 0
         incoming = cm[:, self.rank].clone(); incoming[self.rank] = 0
         moved = int(cm.sum() - cm.diag().sum())
+        self.stats["migrations"] += 1
         if moved == 0:
             return
         payload = torch.cat([self.owned, self.gid.to(torch.float64)[None, :]])     # [10, n]; gid < 2^53 is exact
@@ -213,116 +300,157 @@ class DistSim:
         self.stats["migrated"] += moved
 
     def _exchange_ghosts(self):
-        """steps 2-4 of the module docstring: who needs which of my particles, ship them, upload"""
-        pos = self.owned[:3]
-        if self.n_owned:
-            bb = torch.cat([pos.min(dim=1).values, pos.max(dim=1).values])
-        else:
-            bb = torch.tensor([np.inf] * 3 + [-np.inf] * 3, dtype=torch.float64, device=self.dev)
-        boxes = self._all_gather_rows(bb).numpy()                # [P, 6] on the host
+        """steps 3-5 of the module docstring: who needs which of my particles, ship them, swap them in"""
+        be = self.be
+        boxes = self._all_gather(be.owned_bbox()).cpu().numpy()     # [P, 6] on the host
         r = 2.0 * self.h * (1.0 + 1e-9)
         me_lo, me_hi = boxes[self.rank, :3], boxes[self.rank, 3:]
-        send, counts = [None] * self.P, [0] * self.P
+        mine_ok = bool(np.all(np.isfinite(boxes[self.rank])))
+        peers, sel = [], []
         for q in range(self.P):
             self.send_idx[q] = None
-            if q == self.rank or not np.all(np.isfinite(boxes[q])) or not np.all(np.isfinite(boxes[self.rank])):
+            if q == self.rank or not mine_ok or not np.all(np.isfinite(boxes[q])):
                 continue
             lo, hi = boxes[q, :3] - r, boxes[q, 3:] + r
             if np.any(me_hi < lo) or np.any(me_lo > hi):          # boxes do not touch: nothing to send
                 continue
-            lo_t = torch.as_tensor(lo, device=self.dev)[:, None]
-            hi_t = torch.as_tensor(hi, device=self.dev)[:, None]
-            idx = torch.nonzero(((pos >= lo_t) & (pos <= hi_t)).all(dim=0)).flatten()
-            counts[q] = int(idx.numel())
-            if counts[q]:
-                self.send_idx[q] = idx
-                send[q] = self.owned[:, idx]
-        cm = self._all_gather_rows(torch.tensor(counts, dtype=torch.int64, device=self.dev))
+            peers.append(q)
+            sel.append(np.concatenate([lo, hi]))
+        counts = [0] * self.P
+        if peers:
+            for q, ids in zip(peers, be.select_boxes(np.stack(sel))):
+                counts[q] = int(ids.numel())
+                if counts[q]:
+                    self.send_idx[q] = ids
+        cm = self._all_gather(torch.tensor(counts, dtype=torch.int64)).cpu()
         rc = [int(cm[q, self.rank]) for q in range(self.P)]
+        send = [be.gather(STATE, idx) if idx is not None else None for idx in self.send_idx]
         recv = self._p2p(send, rc, 9)
         first = self.n_owned
-        parts = [self.owned]
+        parts = []
         for q in range(self.P):
             self.ghost_first[q], self.ghost_count[q] = first, rc[q]
             if recv[q] is not None:
                 parts.append(recv[q])
             first += rc[q]
-        allp = torch.cat(parts, dim=1) if len(parts) > 1 else self.owned
-        self.stats["ghosts"] = int(allp.shape[1]) - self.n_owned
-        self.be.upload(allp, self.n_owned)
-        self.in_backend = True
+        if len(parts) == 1:
+            ghosts = parts[0]
+        elif parts:
+            ghosts = torch.cat(parts, dim=1)
+        else:
+            ghosts = torch.empty((9, 0), dtype=torch.float64, device=self.dev)
+        self.stats["ghosts"] = int(ghosts.shape[1])
+        be.replace_ghosts(ghosts)
 
-    def _refresh_ghost_fields(self, names):
-        """ship the listed fields of the particles my peers hold as ghosts; scatter what I receive"""
+    def _refresh_ghost_start(self, names):
+        """ship the listed fields of the particles my peers hold as ghosts (posts the messages)"""
         if self.P == 1:
-            return
+            return None
         send = [self.be.gather(names, idx) if idx is not None else None for idx in self.send_idx]
-        recv = self._p2p(send, self.ghost_count, len(names))
+        return names, self._p2p_start(send, self.ghost_count, len(names))
+
+    def _refresh_ghost_finish(self, handle):
+        """scatter what the peers sent into my ghost slots"""
+        if handle is None:
+            return
+        names, h = handle
+        recv = self._p2p_finish(h)
         for q in range(self.P):
             if recv[q] is not None:
                 self.be.scatter(names, self.ghost_first[q], recv[q])
+
+    def _refresh_ghost_fields(self, names):
+        self._refresh_ghost_finish(self._refresh_ghost_start(names))
+
+    def _reduce(self):
+        """sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied"""
+        allp = self._all_gather(self.be.pack_partials()).to(self.dev)
+        self.be.apply_partials(allp, self.dt_pending)
+        self.dt_pending = False
 
     # ---- the hot path, distributed -----------------------------------------------------------------
     def evaluate(self):
         """one force evaluation: create_tree..find_forces of the reference, [F]:894-898"""
         be = self.be
         if self.pos_dirty:
-            if self.P > 1:
-                if self.in_backend:
-                    self._pull_owned()
-                if self.migrate:
-                    self._migrate()
-                self._exchange_ghosts()
-            elif not self.in_backend:          # single rank: upload once, everything stays on the device
-                be.upload(self.owned, self.n_owned)
+            if not self.in_backend or (self.P > 1 and self.migrate and self.since_migrate >= self.migrate_every):
+                if self.P > 1 and self.migrate:
+                    if self.in_backend:
+                        with self._phase("pull_owned"):
+                            self._pull_owned()
+                    with self._phase("migrate"):
+                        self._migrate()
+                    self.since_migrate = 0
+                with self._phase("upload"):
+                    be.upload(self.owned)
                 self.in_backend = True
-            be.density()
-            self._refresh_ghost_fields(["rho"])
             if self.P > 1:
-                be.refresh_eos()
+                with self._phase("ghost_exchange"):
+                    self._exchange_ghosts()
+            with self._phase("compute"):
+                be.density()
+            with self._phase("ghost_rho"):
+                self._refresh_ghost_fields(["rho"])
+            if self.P > 1:
+                with self._phase("compute"):
+                    be.refresh_eos()
         else:
-            if self.vel_dirty:
-                self._refresh_ghost_fields(["vx", "vy", "vz", "u", "alpha"])
-            be.density()
+            # the density sum needs positions and masses only: it runs while the ghosts' v, u, alpha travel
+            with self._phase("ghost_vel"):
+                pending = self._refresh_ghost_start(["vx", "vy", "vz", "u", "alpha"]) if self.vel_dirty else None
+            with self._phase("compute"):
+                be.density()
+            with self._phase("ghost_vel"):
+                self._refresh_ghost_finish(pending)
             if self.P > 1:
-                be.refresh_eos()
+                with self._phase("compute"):
+                    be.refresh_eos()
         self.pos_dirty = self.vel_dirty = False
-        be.forces()
-        if self.P > 1:
-            s = be.get_sinks()
-            tot = self._allreduce(np.concatenate([s["ax"], s["ay"], s["az"]]), dist.ReduceOp.SUM)
-            ns = s["ax"].size
-            be.set_sink_accel(tot[:ns], tot[ns:2 * ns], tot[2 * ns:])
+        with self._phase("compute"):
+            be.forces()
+        with self._phase("reduce"):
+            self._reduce()
 
-    def next_dt(self, dt: float) -> float:
-        """get_next_timestep, [F]:851-859, with the candidate min-reduced over ranks"""
-        cand = self.be.dt_candidate()
-        if self.P > 1:
-            cand = float(self._allreduce([cand], dist.ReduceOp.MIN)[0])
-        p = self.be.params
-        if cand > 2 * dt and 1.5 * dt < p.dt_max:
-            return 1.5 * dt
-        if cand < 0.5 * dt and dt * 0.5 > p.dt_min:
-            return 0.5 * dt
+    def _step(self):
+        """one iteration of simulate()'s loop body, [F]:889-916, dt and t on the backend"""
+        be = self.be
+        self.evaluate()
+        with self._phase("compute"):
+            be.kick()
+            be.drift()
+        self.pos_dirty = True
+        self.since_migrate += 1
+        self.evaluate()
+        with self._phase("compute"):
+            be.kick()
+            be.dt_candidate_local()          # get_next_timestep's local part, [F]:845-851; reduced with the next exchange
+        self.vel_dirty = True
+        self.dt_pending = True
+
+    def _finish_dt(self):
+        """reduce a pending dt candidate now (end of a run): t += dt and [F]:855-858 on every rank"""
+        if not self.dt_pending:
+            return
+        with self._phase("reduce"):
+            allp = self._all_gather(self.be.pack_partials()).to(self.dev)
+            # the sink accelerations in the blocks are the totals every rank already holds: keep them
+            # (summing them again would multiply by P), only the dt part of the blocks is applied
+            mine = allp[self.rank:self.rank + 1].clone()
+            mine[0, PARTIALS - 1] = allp[:, PARTIALS - 1].min()
+            self.be.apply_partials(mine, True)
+            self.dt_pending = False
+
+    def run(self, nsteps: int, dt: float) -> float:
+        self.be.set_dt(dt, self.t)
+        for _ in range(nsteps):
+            self._step()
+        self._finish_dt()
+        dt, self.t = self.be.get_dt()
         return dt
 
     def step(self, dt: float) -> float:
-        """one iteration of simulate()'s loop body, [F]:889-916; returns the next dt"""
-        be = self.be
-        self.evaluate()
-        be.kick(dt)
-        be.drift(dt)
-        self.pos_dirty = True
-        self.evaluate()
-        be.kick(dt)
-        self.vel_dirty = True
-        self.t += dt
-        return self.next_dt(dt)
-
-    def run(self, nsteps: int, dt: float) -> float:
-        for _ in range(nsteps):
-            dt = self.step(dt)
-        return dt
+        """one step; returns the next dt"""
+        return self.run(1, dt)
 
     def gather_state(self) -> dict:
         """owned state + gid of this rank as numpy (for checks and saves)"""

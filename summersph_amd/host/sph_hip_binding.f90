@@ -42,6 +42,7 @@ module sph_hip_binding
     integer(c_int32_t) :: nlist_capacity, nlist_max
     real(c_double) :: nlist_mean
     integer(c_int64_t) :: grid_builds, nlist_builds, density_passes, force_passes, device_bytes
+    real(c_double) :: nlist_wave_mean
   end type sph_stats
 
   interface

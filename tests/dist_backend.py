@@ -31,10 +31,36 @@ class OracleBackend:
     def set_rank(self, rank, nranks):
         self.rank, self.nranks = rank, nranks
 
-    def upload(self, state, n_owned):
-        self.n, self.n_owned = int(state.shape[1]), int(n_owned)
+    def upload(self, state):
+        self.n = self.n_owned = int(state.shape[1])
         for i, k in enumerate(self.STATE):
             self.f[k] = np.ascontiguousarray(state[i].cpu().numpy(), dtype=np.float64).copy()
+        for k in "rho P c ax ay az du dalpha".split():
+            self.f[k] = np.zeros(self.n)
+        self._ghost_rho = None
+
+    def owned_bbox(self):
+        o = self.n_owned
+        if o == 0:
+            return torch.tensor([np.inf] * 3 + [-np.inf] * 3, dtype=torch.float64)
+        pos = np.stack([self.f[k][:o] for k in "xyz"])
+        return torch.from_numpy(np.concatenate([pos.min(1), pos.max(1)]))
+
+    def select_boxes(self, boxes):
+        o = self.n_owned
+        pos = np.stack([self.f[k][:o] for k in "xyz"])
+        out = []
+        for b in np.asarray(boxes).reshape(-1, 6):
+            inside = np.all((pos >= b[:3, None]) & (pos <= b[3:, None]), axis=0)
+            out.append(torch.from_numpy(np.nonzero(inside)[0].astype(np.int64)))
+        return out
+
+    def replace_ghosts(self, state):
+        g = state.cpu().numpy()
+        o = self.n_owned
+        for i, k in enumerate(self.STATE):
+            self.f[k] = np.ascontiguousarray(np.concatenate([self.f[k][:o], g[i]]))
+        self.n = o + g.shape[1]
         for k in "rho P c ax ay az du dalpha".split():
             self.f[k] = np.zeros(self.n)
         self._ghost_rho = None
@@ -59,8 +85,41 @@ class OracleBackend:
     def get_sinks(self):
         return {k: v.copy() for k, v in self.s.items()}
 
-    def set_sink_accel(self, ax, ay, az):
-        self.s["ax"][:], self.s["ay"][:], self.s["az"][:] = ax, ay, az
+    # dt and t live in the backend (the HIP context keeps them on the device)
+    def set_dt(self, dt, t):
+        self.dt, self.t, self.cand = float(dt), float(t), 0.0
+
+    def get_dt(self):
+        return self.dt, self.t
+
+    def dt_candidate_local(self):
+        self.cand = self._dt_candidate()
+
+    def pack_partials(self):
+        out = np.zeros(193)
+        ns = self.s["x"].size
+        for k, a in enumerate(("ax", "ay", "az")):
+            out[64 * k:64 * k + ns] = self.s[a]
+        out[192] = self.cand
+        return torch.from_numpy(out)
+
+    def apply_partials(self, allp, apply_dt):
+        a = allp.cpu().numpy()
+        ns = self.s["x"].size
+        for k, name in enumerate(("ax", "ay", "az")):
+            tot = np.zeros(ns)
+            for r in range(a.shape[0]):            # rank order, like the device kernel
+                tot = tot + a[r, 64 * k:64 * k + ns]
+            self.s[name][:] = tot
+        if apply_dt:
+            cand = float(np.min(a[:, 192]))
+            dt = self.dt
+            self.t += dt
+            if cand > 2 * dt and 1.5 * dt < self.params.dt_max:
+                dt = 1.5 * dt
+            elif cand < 0.5 * dt and dt * 0.5 > self.params.dt_min:
+                dt = 0.5 * dt
+            self.dt, self.cand = dt, cand
 
     def density(self):
         f = self.f
@@ -103,19 +162,19 @@ class OracleBackend:
                                  C.c_int(self.nq), _p(self.w), _p(self.dw), _p(f["ax"]), _p(f["ay"]), _p(f["az"]),
                                  _p(f["du"]), _p(f["dalpha"]), C.c_int(2))
 
-    def kick(self, dt):
-        f, s = self.f, self.s
+    def kick(self):
+        f, s, dt = self.f, self.s, self.dt
         orc.lib().orc_kick(C.c_int(self.n), _p(f["vx"]), _p(f["vy"]), _p(f["vz"]), _p(f["u"]), _p(f["alpha"]),
                            _p(f["ax"]), _p(f["ay"]), _p(f["az"]), _p(f["du"]), _p(f["dalpha"]), C.c_int(s["x"].size),
                            _p(s["vx"]), _p(s["vy"]), _p(s["vz"]), _p(s["ax"]), _p(s["ay"]), _p(s["az"]), C.c_double(dt))
 
-    def drift(self, dt):
-        f, s = self.f, self.s
+    def drift(self):
+        f, s, dt = self.f, self.s, self.dt
         orc.lib().orc_drift(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["vx"]), _p(f["vy"]), _p(f["vz"]),
                             C.c_int(s["x"].size), _p(s["x"]), _p(s["y"]), _p(s["z"]), _p(s["vx"]), _p(s["vy"]), _p(s["vz"]),
                             C.c_double(dt))
 
-    def dt_candidate(self):
+    def _dt_candidate(self):
         f = self.f
         o = self.n_owned
         a = {k: np.ascontiguousarray(f[k][:o]) for k in "vx vy vz ax ay az u du c".split()}

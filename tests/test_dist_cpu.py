@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nsteps, outdir, ic_rows):
+def _worker(rank, world, port, nsteps, outdir, ic_rows, migrate_every, chunk):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -36,10 +36,10 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows):
     sel = owner == rank
     mine = {k: v[sel] for k, v in gas.items()}
     mine["gid"] = np.nonzero(sel)[0]
-    sim = DistSim(OracleBackend(), mine, sinks, bounds)
+    sim = DistSim(OracleBackend(), mine, sinks, bounds, migrate_every=migrate_every)
     dts = [1e-2]
-    for _ in range(nsteps):
-        dts.append(sim.step(dts[-1]))
+    for _ in range(0, nsteps, chunk):       # chunk > 1: the dt reduction rides on the next step's exchange
+        dts.append(sim.run(chunk, dts[-1]))
     st = sim.gather_state()
     s = sim.be.get_sinks()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), dts=np.array(dts), ghosts=sim.stats["ghosts"],
@@ -48,8 +48,8 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows):
     dist.destroy_process_group()
 
 
-def _run(world, nsteps, rows, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), nsteps, str(tmp_path), rows), nprocs=world, join=True)
+def _run(world, nsteps, rows, tmp_path, migrate_every=8, chunk=1):
+    mp.spawn(_worker, args=(world, _free_port(), nsteps, str(tmp_path), rows, migrate_every, chunk), nprocs=world, join=True)
     parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(world)]
     gid = np.concatenate([p["gid"] for p in parts])
     assert np.array_equal(np.sort(gid), np.arange(gid.size))          # every particle owned exactly once
@@ -58,12 +58,14 @@ def _run(world, nsteps, rows, tmp_path):
     return parts, merged
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_decomposition_invariance_vs_reference_fixture(tmp_path, world):
+@pytest.mark.parametrize("world,chunk", [(2, 1), (3, 1), (2, 5)])
+def test_decomposition_invariance_vs_reference_fixture(tmp_path, world, chunk):
+    """chunk 1: one run() per step (dt reduced at the end of every step); chunk 5: one run(5), the dt candidate of
+    each step travels with the first reduction of the next one"""
     g = load_golden("disc3000_traj")
-    parts, merged = _run(world, 5, g["ic"], tmp_path)
+    parts, merged = _run(world, 5, g["ic"], tmp_path, chunk=chunk)
     for p in parts:
-        assert list(p["dts"]) == list(g["sph_dt_seq"])                # same dt decisions on every rank
+        assert list(p["dts"]) == list(g["sph_dt_seq"])[::chunk]       # same dt decisions on every rank
         assert p["ghosts"] > 0
         assert np.max(np.abs(p["sx"] - g["sph_s5_sx"])) <= 1e-12      # replicated sink stays in sync
         assert np.array_equal(p["sx"], parts[0]["sx"]) and np.array_equal(p["svx"], parts[0]["svx"])
@@ -75,7 +77,7 @@ def test_migration_happens_and_is_lossless(tmp_path):
     from summersph_amd import ic
     rows = ic.keplerian_disc(2500, seed=77, r_in=8.0)
     rows[:-1, 3:6] *= 3.0          # fast particles: many cross the slab edges within a few steps
-    parts, merged = _run(3, 6, rows, tmp_path)
+    parts, merged = _run(3, 6, rows, tmp_path, migrate_every=2)
     assert sum(int(p["migrated"]) for p in parts) > 0
     # single-domain oracle run of the same IC
     from oracle import orc
