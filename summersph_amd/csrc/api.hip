@@ -48,7 +48,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
     ctx_free(c, c->g_left); ctx_free(c, c->g_right); ctx_free(c, c->g_parent); ctx_free(c, c->g_leaf_parent);
     ctx_free(c, c->g_prefix); ctx_free(c, c->g_flag); ctx_free(c, c->g_slot); ctx_free(c, c->g_lvl); ctx_free(c, c->g_rope);
-    ctx_free(c, c->g_leaf_rope); ctx_free(c, c->g_sum); ctx_free(c, c->g_leafA); ctx_free(c, c->g_walkB); ctx_free(c, c->g_leafB);
+    ctx_free(c, c->g_leaf_rope); ctx_free(c, c->g_sum); ctx_free(c, c->g_seg); ctx_free(c, c->g_wrec); ctx_free(c, c->g_leaf_of); ctx_free(c, c->g_leafA); ctx_free(c, c->g_walkB); ctx_free(c, c->g_leafB);
     c->msort_tmp_bytes = 0;
     c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
 }
@@ -99,7 +99,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
         API_TRY(ctx_alloc(c, &c->g_prefix, (size_t)cap, "tree prefix")); API_TRY(ctx_alloc(c, &c->g_flag, (size_t)cap, "tree flags"));
         API_TRY(ctx_alloc(c, &c->g_slot, (size_t)cap, "leaf slots")); API_TRY(ctx_alloc(c, &c->g_lvl, (size_t)cap, "tree levels"));
         API_TRY(ctx_alloc(c, &c->g_rope, (size_t)cap, "tree ropes")); API_TRY(ctx_alloc(c, &c->g_leaf_rope, (size_t)cap, "leaf ropes"));
-        API_TRY(ctx_alloc(c, &c->g_sum, (size_t)cap * 4, "node sums")); API_TRY(ctx_alloc(c, &c->g_leafA, (size_t)cap * 4, "leaf records"));
+        API_TRY(ctx_alloc(c, &c->g_sum, (size_t)cap * 4, "node sums")); API_TRY(ctx_alloc(c, &c->g_leaf_of, (size_t)cap, "slot -> leaf")); API_TRY(ctx_alloc(c, &c->g_wrec, (size_t)cap * 16, "wave walk records")); API_TRY(ctx_alloc(c, &c->g_seg, ((size_t)cap + 64) * 4, "segment tree")); API_TRY(ctx_alloc(c, &c->g_leafA, (size_t)cap * 4, "leaf records"));
         API_TRY(ctx_alloc(c, &c->g_walkB, (size_t)cap * 4, "walk records")); API_TRY(ctx_alloc(c, &c->g_leafB, (size_t)cap * 2, "leaf walk records"));
     }
     c->cap = cap;

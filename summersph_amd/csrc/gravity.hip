@@ -24,6 +24,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "pair_common.hpp"
 
@@ -68,7 +70,8 @@ struct TreeArrays {
     int32_t *left, *right, *parent;     // internal nodes
     int32_t *leaf_parent;               // leaves
     int32_t *prefix;                    // internal: common prefix length (bits of the 64-bit word)
-    int32_t *flag;                      // bottom-up arrival counters
+    int32_t *other;                     // internal: the far end j of the node's leaf range [min(i,j), max(i,j)]
+    double4 *seg;                       // segment tree over the leaves in key order (levels 1.., see seg_stage)
     double4 *sum;                       // internal: sum m x, sum m y, sum m z, sum m  -> later com + mass
     double4 *leafA;                     // leaves in key order: x y z m
     int32_t *slot;                      // leaf -> cell-sorted slot
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(GB) void radix_tree(const uint64_t *__restrict__ k,
     if (L < 0) t.leaf_parent[~L] = i; else t.parent[L] = i;
     if (Rr < 0) t.leaf_parent[~Rr] = i; else t.parent[Rr] = i;
     if (i == 0) t.parent[0] = -1;
-    t.flag[i] = 0;
+    t.other[i] = j;
 }
 
 __global__ __launch_bounds__(GB) void leaf_data(const uint32_t *__restrict__ vals, const double4 *__restrict__ drec, int n,
@@ -118,32 +121,62 @@ __global__ __launch_bounds__(GB) void leaf_data(const uint32_t *__restrict__ val
     t.slot[j] = (int32_t)s;
 }
 
-// bottom-up sums: the second thread to arrive at a node finds both children finished
-__global__ __launch_bounds__(GB) void node_sums(int n, TreeArrays t) {
-    const int j = blockIdx.x * GB + threadIdx.x;
-    if (j >= n || n < 2) return;
-    int node = t.leaf_parent[j];
-    while (node >= 0) {
-        __threadfence();
-        if (atomicAdd(&t.flag[node], 1) == 0) return;
-        __threadfence();
-        const int L = t.left[node], Rr = t.right[node];
-        double4 a, b;
-        if (L < 0) { const double4 p = t.leafA[~L]; a = make_double4(p.w * p.x, p.w * p.y, p.w * p.z, p.w); }
-        else { const double *q = reinterpret_cast<const double *>(&t.sum[L]);
-               a = make_double4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-        if (Rr < 0) { const double4 p = t.leafA[~Rr]; b = make_double4(p.w * p.x, p.w * p.y, p.w * p.z, p.w); }
-        else { const double *q = reinterpret_cast<const double *>(&t.sum[Rr]);
-               b = make_double4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-        double *o = reinterpret_cast<double *>(&t.sum[node]);
-        __hip_atomic_store(o, a.x + b.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 1, a.y + b.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 2, a.z + b.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 3, a.w + b.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        node = t.parent[node];
+// Node sums.  Every internal node of the radix tree covers a contiguous range of leaves (key order), so its mass
+// and first moments are a range sum over the leaves.  A segment tree over the leaf array (level l entry k = sum of
+// leaves [k 2^l, (k+1) 2^l), built in stages of SEG_LV levels per launch, LDS ping-pong) answers every range with
+// 2 log2(length) entries, summed small to large on either side -- pairwise accuracy, a fixed order (reproducible),
+// and no communication between workgroups (a bottom-up pass with arrival counters needs device-scope fences, which
+// write back the XCD's L2 on this chip: 5.8 ms for 1e6 leaves, against 0.1 ms for this scheme).
+constexpr int SEG_LV = 9;                       // levels per stage: a block reduces 512 entries
+constexpr int SEG_MAX_LEVELS = 40;
+struct SegLevels {
+    int64_t off[SEG_MAX_LEVELS];                // off[l]: first entry of level l in seg[] (level 0 = the leaves, not stored)
+    int64_t cnt[SEG_MAX_LEVELS];
+    int levels;
+};
+
+__device__ __forceinline__ double4 leaf_moment(const double4 p) { return make_double4(p.w * p.x, p.w * p.y, p.w * p.z, p.w); }
+__device__ __forceinline__ double4 add4(const double4 a, const double4 b) { return make_double4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// stage: from level L0 (the leaves if L0 == 0) up to level L0 + SEG_LV
+__global__ __launch_bounds__(256) void seg_stage(SegLevels sl, int L0, const double4 *__restrict__ leafA, double4 *__restrict__ seg) {
+    __shared__ double4 buf[2][512];
+    const int64_t base = (int64_t)blockIdx.x * 512;
+    const int64_t c0 = sl.cnt[L0];
+    for (int e = threadIdx.x; e < 512; e += 256) {
+        const int64_t k = base + e;
+        double4 v = make_double4(0, 0, 0, 0);
+        if (k < c0) v = L0 == 0 ? leaf_moment(leafA[k]) : seg[sl.off[L0] + k];
+        buf[0][e] = v;
     }
+    __syncthreads();
+    int cur = 0;
+    for (int l = 1; l <= SEG_LV && L0 + l < sl.levels; l++) {
+        const int width = 512 >> l;
+        const int64_t kb = base >> l;
+        for (int e = threadIdx.x; e < width; e += 256) {
+            const double4 v = add4(buf[cur][2 * e], buf[cur][2 * e + 1]);     // entries past the end are zero
+            buf[cur ^ 1][e] = v;
+            if (kb + e < sl.cnt[L0 + l]) seg[sl.off[L0 + l] + kb + e] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(GB) void node_sums_seg(int n, SegLevels sl, TreeArrays t) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int j = t.other[i];
+    int64_t l = min(i, j), r = (int64_t)max(i, j) + 1;
+    double4 accl = make_double4(0, 0, 0, 0), accr = make_double4(0, 0, 0, 0);
+    int lev = 0;
+    while (l < r) {
+        if (l & 1) { accl = add4(accl, lev == 0 ? leaf_moment(t.leafA[l]) : t.seg[sl.off[lev] + l]); l++; }
+        if (r & 1) { r--; accr = add4(accr, lev == 0 ? leaf_moment(t.leafA[r]) : t.seg[sl.off[lev] + r]); }
+        l >>= 1; r >>= 1; lev++;
+    }
+    t.sum[i] = add4(accl, accr);
 }
 
 // centre of mass, octree level, ropes
@@ -259,6 +292,105 @@ __global__ __launch_bounds__(GB) void grav_walk(int n, TreeArrays t, RootBox rb,
     ax[i] = a0; ay[i] = a1; az[i] = a2;
 }
 
+// One 64-byte record per node for the wave walk, leaves behind the internal nodes (unified index: internal i -> i,
+// leaf j -> n - 1 + j): centre of mass + mass, the squared edge of the node's smallest box (-1 for a leaf: always
+// accepted), both successors, and for leaves the cell-sorted slot (to recognise the target's own leaf).
+struct alignas(64) WalkRec {
+    double cx, cy, cz, m;
+    double size2;
+    int32_t next_open, next_skip;       // unified indices, END terminates
+    int32_t slot, pad0;
+    double pad1;
+};
+
+__device__ __forceinline__ int unified(int node, int n) { return node == END ? END : (node < 0 ? n - 1 + ~node : node); }
+
+__global__ __launch_bounds__(GB) void node_wave_records(int n, TreeArrays t, RootBox rb, WalkRec *__restrict__ rec,
+                                                        int32_t *__restrict__ leaf_of) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i < n - 1) {
+        const int4 wb = t.walkB[i];
+        const double4 c = t.sum[i];
+        const double size = ldexp(rb.size, -wb.z);
+        WalkRec r{c.x, c.y, c.z, c.w, size * size, unified(wb.x, n), unified(wb.y, n), -1, 0, 0.0};
+        rec[i] = r;
+    }
+    if (i < n) {
+        const int2 lb = t.leafB[i];
+        const double4 c = t.leafA[i];
+        const int nx = unified(lb.x, n);
+        WalkRec r{c.x, c.y, c.z, c.w, -1.0, nx, nx, lb.y, 0, 0.0};
+        rec[n - 1 + i] = r;
+        leaf_of[lb.y] = i;                   // cell-sorted slot -> leaf (key order)
+    }
+}
+
+// The same walk, one WAVE per 64 consecutive targets of the cell-sorted order (a column of grid cells; taking them in
+// key order instead makes the union of the 64 walks 24 % larger).  The wave visits the union of its lanes' walks in the same depth-first order: the
+// current node is wave-uniform (its record comes through the scalar cache, one 64-byte read for 64 lanes), every
+// active lane applies its own acceptance test, and the wave descends as soon as one lane needs to.  A lane that
+// accepted the node sleeps until the walk leaves that subtree -- it wakes at the node's rope, which every exit
+// from the subtree reaches.  Each lane therefore accumulates exactly the contributions of its own walk, in the same
+// order as grav_walk (kept as the per-lane reference implementation, SPH_GRAV_WAVE=0).
+__global__ __launch_bounds__(GB) void grav_walk_wave(int n, const WalkRec *__restrict__ rec, const double4 *__restrict__ leafA,
+                                                     const int32_t *__restrict__ leaf_of, const double *__restrict__ hvar,
+                                                     double hfix, double soft2, double theta, double G,
+                                                     const double *__restrict__ gt, int nq, double dq, double *__restrict__ ax,
+                                                     double *__restrict__ ay, double *__restrict__ az, const int32_t *__restrict__ orig,
+                                                     int32_t n_owned, unsigned long long *__restrict__ stats) {
+    const int i = xcd_chunk(blockIdx.x, gridDim.x) * GB + threadIdx.x;       // target: cell-sorted slot
+    const int self = i < n ? i : n - 1;
+    const bool live = i < n && orig[self] < n_owned;
+    const int j = leaf_of[self];                                              // its leaf (key order)
+    const double4 p = leafA[j];
+    const double hp = hvar ? hvar[self] : hfix;
+    const double inv_hp = 1.0 / hp, inv_dq = 1.0 / dq, theta2 = theta * theta, rsoft2 = 4.0 * hp * hp;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    bool active = live;                       // the root is an octree node by construction
+    int resume = END;
+    int node = n >= 2 ? 0 : END;
+    const int own = n - 1 + j;                // unified index of the target's own leaf
+    unsigned visits = 0, sums = 0;
+    while (node != END) {
+        node = __builtin_amdgcn_readfirstlane(node);
+        if (!active && resume == node) active = true;
+        const WalkRec r = rec[node];
+        const double d0 = p.x - r.cx, d1 = p.y - r.cy, d2c = p.z - r.cz;  // [F]:274
+        const double d2 = (d0 * d0 + d1 * d1 + d2c * d2c) + soft2;        // [F]:275
+        const bool accept = r.size2 < theta2 * d2;                        // [F]:278, see grav_walk; leaves: size2 = -1
+        const bool open_any = __any(active && !accept);
+        if (active && accept && node != own && r.m > 0.0) {               // own leaf: direction = 0, contributes nothing
+            double dist, rs;
+            fast_sqrt_rsqrt(d2, dist, rs);
+            double W = 1.0;                                                // [F]:129-146: 1 beyond the softening support
+            if (d2 <= rsoft2) {
+                const double qi = dist * inv_hp;
+                if (qi <= 2.0) {
+                    const double tq = qi * inv_dq;
+                    const int k = min((int)tq, nq - 1);
+                    const double a = tq - (double)k;
+                    W = (1.0 - a) * gt[k] + a * gt[k + 1];
+                }
+            }
+            const double f = (G * r.m) * W * (rs * rs * rs);              // [F]:281
+            a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
+            sums++;
+        }
+        visits++;
+        if (open_any) {
+            if (active && accept) { active = false; resume = r.next_skip; }   // done with this subtree
+            node = r.next_open;
+        } else {
+            node = r.next_skip;
+        }
+    }
+    if (live) { ax[i] = a0; ay[i] = a1; az[i] = a2; }
+    if (stats) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(&stats[0], (unsigned long long)visits);
+        atomicAdd(&stats[1], (unsigned long long)sums);
+    }
+}
+
 }  // namespace
 
 #define GR_CHECK2(expr)                                                     \
@@ -281,7 +413,7 @@ hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes) {
 static TreeArrays tree_arrays(sph_ctx *c) {
     TreeArrays t;
     t.left = c->g_left; t.right = c->g_right; t.parent = c->g_parent; t.leaf_parent = c->g_leaf_parent; t.prefix = c->g_prefix;
-    t.flag = c->g_flag; t.sum = reinterpret_cast<double4 *>(c->g_sum); t.leafA = reinterpret_cast<double4 *>(c->g_leafA);
+    t.other = c->g_flag; t.seg = reinterpret_cast<double4 *>(c->g_seg); t.sum = reinterpret_cast<double4 *>(c->g_sum); t.leafA = reinterpret_cast<double4 *>(c->g_leafA);
     t.slot = c->g_slot; t.lvl = c->g_lvl; t.rope = c->g_rope; t.leaf_rope = c->g_leaf_rope;
     t.walkB = reinterpret_cast<int4 *>(c->g_walkB); t.leafB = reinterpret_cast<int2 *>(c->g_leafB);
     return t;
@@ -310,10 +442,22 @@ int gravity_tree_build(sph_ctx *c) {
     leaf_data<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->mvals_alt, drec, (int)n, t);
     if (n >= 2) {
         radix_tree<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->mkeys_alt, (int)n, t);
-        node_sums<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
+        SegLevels sl{};
+        sl.cnt[0] = n; sl.off[0] = 0; sl.levels = 1;
+        int64_t off = 0;
+        while (sl.cnt[sl.levels - 1] > 1 && sl.levels < SEG_MAX_LEVELS) {
+            sl.cnt[sl.levels] = (sl.cnt[sl.levels - 1] + 1) / 2;
+            sl.off[sl.levels] = off;
+            off += sl.cnt[sl.levels];
+            sl.levels++;
+        }
+        for (int L0 = 0; L0 + 1 < sl.levels; L0 += SEG_LV)
+            seg_stage<<<dim3((unsigned)((sl.cnt[L0] + 511) / 512)), dim3(256), 0, c->stream>>>(sl, L0, t.leafA, t.seg);
+        node_sums_seg<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, sl, t);
     }
     node_finish<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
     node_walk_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
+    node_wave_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t, rb, reinterpret_cast<WalkRec *>(c->g_wrec), c->g_leaf_of);
     GR_CHECK2(hipGetLastError());
     return SPH_OK;
 }
@@ -325,6 +469,29 @@ hipError_t launch_gravity(sph_ctx *c) {
     for (int a = 0; a < 3; a++) rb.c[a] = c->root_box[a];
     rb.size = c->root_box[3];
     const double soft2 = 0.001 * 2.5;                                   // 0.001_dp*smoothing, MODULE constant ([F]:275, [V]:296)
+    static int wave_walk = -1;
+    if (wave_walk < 0) { const char *e = getenv("SPH_GRAV_WAVE"); wave_walk = e ? atoi(e) : 1; }
+    if (wave_walk) {
+        TreeArrays ta = tree_arrays(c);
+        unsigned long long *stats = nullptr;
+        if (wave_walk == 2) {                                           // debug: visit / contribution counts
+            if (hipMalloc(reinterpret_cast<void **>(&stats), 16) != hipSuccess) return hipGetLastError();
+            (void)hipMemsetAsync(stats, 0, 16, c->stream);
+        }
+        grav_walk_wave<<<dim3((unsigned)((n + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
+            (int)n, reinterpret_cast<const WalkRec *>(c->g_wrec), ta.leafA, c->g_leaf_of, c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
+            c->p.theta, c->p.G, c->grav_tab, c->p.nq, 2.0 / c->p.nq, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
+            (int32_t)c->n_owned, stats);
+        if (stats) {
+            unsigned long long h[2] = {0, 0};
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpy(h, stats, 16, hipMemcpyDeviceToHost);
+            (void)hipFree(stats);
+            fprintf(stderr, "[grav_walk_wave] n=%lld wave visits/wave=%.1f contributions/particle=%.1f\n", (long long)n,
+                    (double)h[0] / (double)((n + 63) / 64), (double)h[1] / (double)n);
+        }
+        return hipGetLastError();
+    }
     grav_walk<<<dim3((unsigned)((n + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
         (int)n, tree_arrays(c), rb, reinterpret_cast<const double4 *>(c->drec), c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
         c->p.theta, c->p.G, c->grav_tab, c->p.nq, 2.0 / c->p.nq, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,

@@ -106,6 +106,9 @@ struct sph_ctx {
     int32_t *g_left = nullptr, *g_right = nullptr, *g_parent = nullptr, *g_leaf_parent = nullptr, *g_prefix = nullptr;
     int32_t *g_flag = nullptr, *g_slot = nullptr, *g_lvl = nullptr, *g_rope = nullptr, *g_leaf_rope = nullptr;
     double *g_sum = nullptr, *g_leafA = nullptr;     // 4 doubles per node / leaf
+    int32_t *g_leaf_of = nullptr;                    // cell-sorted slot -> leaf index
+    double *g_wrec = nullptr;                        // 64-byte walk records, 2 cap of them (gravity.hip WalkRec)
+    double *g_seg = nullptr;                         // segment tree of leaf moments: 4 doubles x (cap + 64)
     int32_t *g_walkB = nullptr, *g_leafB = nullptr;  // int4 per node, int2 per leaf: packed walk pointers
     double *grav_tab = nullptr;                      // softening table, [F]:81-101
 
