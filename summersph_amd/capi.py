@@ -12,6 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsummersph_hip.so")
+LIB_PATH = os.environ.get("SUMMERSPH_LIB", LIB_PATH)      # A/B builds of the same ABI (profiles/)
 _D = C.POINTER(C.c_double)
 
 FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha", "h", "omega"]
