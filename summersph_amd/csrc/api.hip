@@ -42,7 +42,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->drec); ctx_free(c, c->frec);
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
-    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max);
+    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail);
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
@@ -82,6 +82,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
         API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
         API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
+        API_TRY(ctx_alloc(c, &c->ntail, (size_t)cap, "margin counts"));
     }
     {   // octree path keys: leaf boxes (variable h), self-gravity tree, accretion
         API_TRY(ctx_alloc(c, &c->mkeys, (size_t)cap, "octree keys"));
@@ -444,7 +445,7 @@ int64_t sph_count(const sph_ctx *c) { return c ? c->n : -1; }
 
 static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMemcpyKind kind) {
     if (!c) return SPH_ERR_ARG;
-    if (n < 0 || n > (c->variable ? 1000000000LL : 2000000000LL)) { c->err = "sph_upload: bad n"; return SPH_ERR_ARG; }
+    if (n < 0 || n > (c->variable ? 500000000LL : 2000000000LL)) { c->err = "sph_upload: bad n"; return SPH_ERR_ARG; }
     for (int k = 0; k < 8; k++)
         if (n > 0 && !src[k]) { c->err = "sph_upload: null array"; return SPH_ERR_ARG; }
     DeviceGuard g(c->device);

@@ -126,6 +126,7 @@ struct sph_ctx {
     // nlist[(w*nl_cap + k)*64 + lane]  -> a wave reads 64 consecutive ints per k
     int32_t *nlist = nullptr; int32_t nl_cap = 0; int64_t nl_waves_cap = 0;
     int32_t *ncount = nullptr; int32_t *wave_max = nullptr;
+    int32_t *ntail = nullptr;        // variable h: entries of the margin shell, stored from the end of the lane's column
     int32_t nl_max = 0; double nl_mean = 0.0;
 
     // kernel tables on the device

@@ -35,7 +35,10 @@ namespace {
 
 constexpr int VBLOCK = 256;
 constexpr int LEVELS = 21;            // 63-bit path keys
-constexpr uint32_t FLAG_D = 0x80000000u, FLAG_F = 0x40000000u, IDX_MASK = 0x3fffffffu;
+constexpr uint32_t FLAG_D = 0x80000000u, FLAG_F = 0x40000000u, FLAG_R = 0x20000000u, IDX_MASK = 0x1fffffffu;
+// calc_smoothing re-evaluates rho with a trial length h' > h: the list also keeps (behind the D/F entries, from the
+// last row of the lane's column downwards) the particles whose leaf the body's walk reaches within 2 h (1 + margin)
+constexpr double H_MARGIN = 1.1;
 
 struct RootBox { double c[3]; double size; };
 
@@ -143,7 +146,8 @@ __device__ __forceinline__ double axis_gap2(double p, double lo, double e) {
 }
 
 // ---- neighbour list ---------------------------------------------------------------------------------
-// entry = j | FLAG_D (j counts in i's density sum) | FLAG_F (pair {i,j} counts in the force sums)
+// entry = j | FLAG_D (j counts in i's density sum) | FLAG_F (pair {i,j} counts in the force sums) | FLAG_R (i's walk
+// reaches j's leaf; what update_h needs to know for a trial h)
 // layout: 4-packed, wave-strided (entry k of lane l in wave w = component k%4 of the int4 at
 // nlist4[(w*cap/4 + k/4)*64 + l]); the evaluation kernels read it in lockstep.
 __device__ __forceinline__ size_t voff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
@@ -152,15 +156,16 @@ __device__ __forceinline__ size_t voff(int k) { return (size_t)(k >> 2) * 256 + 
 // the candidates of a 256-particle workgroup lie in ONE contiguous interval of the sorted order (all
 // columns within R of the workgroup's columns); it is staged chunk-wise with coalesced loads and each lane
 // scans its own cells out of LDS instead of gathering every candidate through the TA.
-constexpr int T_NV = 1024;
+constexpr int T_NV = 512;           // candidates per staged chunk: {x,y,z,h}, leaf box and id of each (68 B)
 
 __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, double h_glob, const double4 *__restrict__ prec,
                                                         const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
-                                                        int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
-                                                        int32_t *__restrict__ flags) {
-    __shared__ double4 tile[T_NV];
+                                                        int32_t *__restrict__ ncount, int32_t *__restrict__ ntail,
+                                                        int32_t *__restrict__ wave_max, int32_t *__restrict__ flags) {
+    __shared__ double4 tile[T_NV], tile_l[T_NV];
+    __shared__ int32_t tile_o[T_NV];
     __shared__ int s_lo[VBLOCK / WAVE], s_hi[VBLOCK / WAVE];
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -175,14 +180,15 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     const int s0 = g.s[0], s1 = g.s[1], s2 = g.s[2];
     const int d0 = g.dim[s0], d1 = g.dim[s1], d2 = g.dim[s2];
     const double e = 1.0 / g.inv_edge;
-    const double hi = pi.w;
-    const double rg = 2.0 * fmax(hi, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
-    const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
+    const double hi = pi.w, him = pi.w * H_MARGIN;
+    const double rg = 2.0 * fmax(him, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
+    const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12), rim2 = 4.0 * him * him * (1.0 + 1e-12);
     const int c1lo = max(cc[1] - R, 0), c1hi = min(cc[1] + R, d1 - 1);
     const int c0lo = max(cc[0] - R, 0), c0hi = min(cc[0] + R, d0 - 1);
-    int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
-    int4 buf = make_int4(0, 0, 0, 0);
-    int cnt = 0;
+    const int cap4 = cap >> 2;
+    int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * cap4) * 64 + lane;
+    int4 buf = make_int4(0, 0, 0, 0), tbuf = make_int4(0, 0, 0, 0);
+    int cnt = 0, tcnt = 0;
 
     for (int o2 = -R; o2 <= R; o2++) {
         const int c2 = cc[2] + o2;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
         for (int cb = lo; cb < hiv; cb += T_NV) {
             const int ce = min(cb + T_NV, hiv);
             __syncthreads();
-            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) tile[t] = prec[cb + t];
+            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) { tile[t] = prec[cb + t]; tile_l[t] = lrec[cb + t]; tile_o[t] = orig[cb + t]; }
             __syncthreads();
             if (!use2) continue;
             // per-lane walk over this lane's own columns and cells (lanes of different columns advance in
@@ -220,24 +226,31 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                     const int jb = max(cell_start[row + c0], cb), je = min(cell_start[row + c0 + 1], ce);
                     if (jb >= je) continue;
                     const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
-                    const double rc = 2.0 * fmax(hi, cell_hmax[row + c0]);
+                    const double rc = 2.0 * fmax(him, cell_hmax[row + c0]);
                     if (gap > rc * rc * (1.0 + 1e-12)) continue;
                     for (int j = jb; j < je; j++) {
                         const double4 pj = tile[j - cb];
                         const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                         const double r2 = dx * dx + dy * dy + dz * dz;
-                        const double hm = fmax(hi, pj.w);
+                        const double hm = fmax(him, pj.w);
                         if (r2 <= 4.0 * hm * hm * (1.0 + 1e-12) && j != (int)i) {
-                            const double4 lj = lrec[j];
+                            const double4 lj = tile_l[j - cb];
                             const bool rij = reaches(lj, pi.x, pi.y, pi.z);       // i's walk reaches j's leaf
                             const bool inD = rij && r2 <= ri2;                    // [V]:479 + kernel support of h_i
-                            const bool inF = oi > orig[j] ? rij : reaches(li, pj.x, pj.y, pj.z);   // [V]:383
+                            const double hf = fmax(hi, pj.w);
+                            const bool inF = r2 <= 4.0 * hf * hf * (1.0 + 1e-12) &&
+                                             (oi > tile_o[j - cb] ? rij : reaches(li, pj.x, pj.y, pj.z));   // [V]:383
+                            const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u) | (rij ? FLAG_R : 0u));
                             if (inD || inF) {
-                                const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u));
                                 const int q4 = cnt & 3;
                                 if (q4 == 0) buf.x = ent; else if (q4 == 1) buf.y = ent; else if (q4 == 2) buf.z = ent; else buf.w = ent;
                                 if (q4 == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
                                 cnt++;
+                            } else if (rij && r2 <= rim2) {                       // margin shell: only a trial h can need it
+                                const int q4 = tcnt & 3;
+                                if (q4 == 0) tbuf.x = ent; else if (q4 == 1) tbuf.y = ent; else if (q4 == 2) tbuf.z = ent; else tbuf.w = ent;
+                                if (q4 == 3 && tcnt < cap) mine[(size_t)(cap4 - 1 - (tcnt >> 2)) * 64] = tbuf;
+                                tcnt++;
                             }
                         }
                     }
@@ -246,11 +259,14 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
         }
     }
     if ((cnt & 3) != 0 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
-    if (i < n) ncount[i] = live ? cnt : 0;
+    if ((tcnt & 3) != 0 && tcnt < cap) mine[(size_t)(cap4 - 1 - (tcnt >> 2)) * 64] = tbuf;
+    if (i < n) { ncount[i] = live ? cnt : 0; ntail[i] = live ? tcnt : 0; }
     const int wm = wave_max_i32(live ? cnt : 0);
+    // rows needed: the D/F entries from the top, the margin entries from the bottom of the lane's column
+    const int need = wave_max_i32(live ? 4 * (((cnt + 3) >> 2) + ((tcnt + 3) >> 2)) : 0);
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
-        if (wm > 0) atomicMax(&flags[1], wm);
+        if (need > 0) atomicMax(&flags[1], need);
     }
 }
 
@@ -467,17 +483,60 @@ __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec,
     om = 1.0 + (hn / (3.0 * r0)) * oa;                                                     // [V]:535
 }
 
+// the same sums from the body's neighbour list: valid while the trial length stays inside the margin shell the list
+// was built with (hn <= H_MARGIN * h of the build); entries are tested as density_one tests its candidates
+__device__ void density_list(const double4 *__restrict__ drec, const int4 *__restrict__ mine, int cap4, int cnt, int tcnt,
+                             const double *__restrict__ w_tab, const double *__restrict__ dw_tab, const PairConst &pc,
+                             const double4 &pi, double hn, double &rho, double &om) {
+    const double n3 = pc.kernel_pi * (hn * hn * hn), n4 = pc.kernel_pi * ((hn * hn) * (hn * hn));
+    double r0 = 0.0, oa = 0.0;
+    {   // the body itself (r = 0; its own leaf is always reached)
+        const double Wj = w_tab[0] / n3, dWj = dw_tab[0] / n4;
+        const double W_h = -(0.0 * dWj - 3.0 * Wj) / hn;
+        r0 = r0 + pi.w * Wj;
+        oa = oa + pi.w * W_h;
+    }
+    for (int k = 0; k < cnt + tcnt; k++) {
+        const int kk = k < cnt ? k : k - cnt;
+        const int4 q = k < cnt ? mine[(size_t)(kk >> 2) * 64] : mine[(size_t)(cap4 - 1 - (kk >> 2)) * 64];
+        const int c4 = kk & 3;
+        const uint32_t ent = (uint32_t)(c4 == 0 ? q.x : c4 == 1 ? q.y : c4 == 2 ? q.z : q.w);
+        if (!(ent & FLAG_R)) continue;
+        const double4 pj = drec[ent & IDX_MASK];
+        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
+        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+        if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) continue;
+        const double dr = sqrt(r2);
+        const double qi = dr / hn;
+        if (qi > 2.0) continue;
+        int kq = min((int)(qi / pc.dq), pc.nq - 1);
+        const double a = (qi - kq * pc.dq) / pc.dq;
+        const double Wj = ((1.0 - a) * w_tab[kq] + a * w_tab[kq + 1]) / n3;
+        const double dWj = ((1.0 - a) * dw_tab[kq] + a * dw_tab[kq + 1]) / n4;
+        const double W_h = -(dr * dWj - 3.0 * Wj) / hn;                               // [V]:487
+        r0 = r0 + pj.w * Wj;
+        oa = oa + pj.w * W_h;
+    }
+    rho = r0;
+    om = 1.0 + (hn / (3.0 * r0)) * oa;                                                 // [V]:535
+}
+
 __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst pc, const double4 *__restrict__ drec,
                                                           const double4 *__restrict__ lrec, const int32_t *__restrict__ cell_start,
                                                           const double *__restrict__ w_tab, const double *__restrict__ dw_tab,
                                                           int64_t n, const double *__restrict__ h_old, double *__restrict__ h_out,
                                                           double *__restrict__ rho, double *__restrict__ omega,
-                                                          const int32_t *__restrict__ orig, int32_t n_owned) {
+                                                          const int32_t *__restrict__ orig, int32_t n_owned,
+                                                          const int32_t *__restrict__ nlist, int32_t cap,
+                                                          const int32_t *__restrict__ ncount, const int32_t *__restrict__ ntail) {
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
     if (i >= n) return;
     const double h0 = h_old[i];
     if (orig[i] >= n_owned) { h_out[i] = h0; return; }
     const double4 pi = drec[i];
+    const int cap4 = cap >> 2;
+    const int4 *mine = reinterpret_cast<const int4 *>(nlist) + ((size_t)(i >> 6) * cap4) * 64 + (i & 63);
+    const int cnt = min(ncount[i], cap), tcnt = ntail[i];
     double r = rho[i], om = omega[i];
     double old_len = h0;
     double t = pc.eta / h0;
@@ -486,7 +545,8 @@ __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst 
         bool touched = false;
         while (((hn - old_len) / old_len) > pc.h_tol && hn < pc.h_iter_cap) {            // [V]:529
             old_len = hn;
-            density_one(g, drec, lrec, cell_start, w_tab, dw_tab, pc, pi, hn, r, om);    // [V]:531-535
+            if (hn <= H_MARGIN * h0) density_list(drec, mine, cap4, cnt, tcnt, w_tab, dw_tab, pc, pi, hn, r, om);
+            else density_one(g, drec, lrec, cell_start, w_tab, dw_tab, pc, pi, hn, r, om);    // [V]:531-535
             touched = true;
             t = pc.eta / hn;
             hn = hn * (1.0 + ((pi.w * (t * t * t)) / r - 1.0) / (3.0 * om));             // [V]:538
@@ -563,13 +623,13 @@ int varh_leaf_build(sph_ctx *c) {
 int varh_nlist_build(sph_ctx *c) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
-    const int R = std::max(1, (int)std::ceil(2.0 * c->h_max_glob * c->grid.inv_edge * (1.0 + 1e-9)));
+    const int R = std::max(1, (int)std::ceil(2.0 * H_MARGIN * c->h_max_glob * c->grid.inv_edge * (1.0 + 1e-9)));
     const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
     for (int attempt = 0; attempt < 8; attempt++) {
         VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_v_tiled<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
             c->grid, R, c->h_max_glob, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
-            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->wave_max, c->d_flags);
+            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->d_flags);
         VH_CHECK(hipGetLastError());
         VH_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         VH_CHECK(hipStreamSynchronize(c->stream));
@@ -615,7 +675,8 @@ hipError_t launch_update_h(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     update_h_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
         c->grid, pc, reinterpret_cast<const double4 *>(c->drec), reinterpret_cast<const double4 *>(c->lrec), c->cell_start,
-        c->w_tab, c->dw_tab, c->n, c->f[SPH_F_H], c->h_new, c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->orig, (int32_t)c->n_owned);
+        c->w_tab, c->dw_tab, c->n, c->f[SPH_F_H], c->h_new, c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->orig, (int32_t)c->n_owned,
+        c->nlist, c->nl_cap, c->ncount, c->ntail);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) std::swap(c->f[SPH_F_H], c->h_new);
     return e;
