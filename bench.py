@@ -69,9 +69,32 @@ def cpu_baseline(n_total, nngb, seconds_target=15.0):
     for _ in range(k):
         dt = o.step(dt)
     t1 = time.perf_counter()
+    # one thread, on the calibration-size disc (the unmodified reference is serial: SURVEY.md 5)
+    rows = ic.keplerian_disc(20000, seed=1, nngb=nngb)
+    gas, sinks = ic.split_rows(rows)
+    o1 = orc.Oracle(gas, sinks, nthreads=1)
+    s0 = time.perf_counter(); o1.step(1e-2); s1 = time.perf_counter()
     return {"value": k * n_s / (t1 - t0), "unit": "particle-steps/s", "cores": threads, "kind": "port",
             "sample": f"{k} full step(s) (2 density + 2 force passes, kick/drift/dt each) of a {n_s}-particle disc of "
-                      f"the same surface density, OpenMP x{threads}, {t1 - t0:.1f} s"}
+                      f"the same surface density, OpenMP x{threads}, {t1 - t0:.1f} s",
+            "single_thread_value": 20000 / (s1 - s0),
+            "single_thread_sample": f"1 full step of a 20000-particle disc of the same surface density, {s1 - s0:.1f} s"}
+
+
+def stream_copy_gbs(torch, device, nbytes=1 << 30, reps=5):
+    """device-to-device copy rate (bytes read + bytes written per second): the practical HBM ceiling of this box,
+    measured in the same run"""
+    src = torch.empty(nbytes // 8, dtype=torch.float64, device=f"cuda:{device}").fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    ev1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
 def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags):
@@ -231,6 +254,9 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
             "final_dt": dt, "device_bytes": st.device_bytes,
         }
+        copy_gbs = stream_copy_gbs(torch, local_rank)
+        out["roofline"]["stream_copy_GBs"] = copy_gbs
+        out["roofline"]["frac_of_stream_copy"] = achieved / copy_gbs
         if sim is not None and sim.profile:
             out["dist_phase_ms_per_step_rank0"] = {k: 1e3 * v / args.steps for k, v in sim.phase_s.items()}
             out["dist_stats_rank0"] = dict(sim.stats)

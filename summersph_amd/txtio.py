@@ -57,3 +57,17 @@ def read_snapshot(path: str):
         else:
             gas.append(vals[i:i + 9]); i += 9
     return np.asarray(gas).reshape(-1, 9), np.asarray(sinks).reshape(-1, 8)
+
+
+def read_snapshot_v(path: str):
+    """Save file of the variable-h host (one record per line): gas rows (n,10) x y z vx vy vz u m alpha h,
+    sink rows (ns,8) with u written as 0 ("SUMMER_SPH - Variable.f90":921-940)."""
+    gas, sinks = [], []
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            v = [float(t.replace("D", "E")) for t in line.split()]
+            if not v:
+                continue
+            (sinks if len(v) == 8 and v[6] == 0.0 else gas).append(v)
+    return np.asarray(gas).reshape(-1, 10), np.asarray(sinks).reshape(-1, 8)

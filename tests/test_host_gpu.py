@@ -12,17 +12,18 @@ from summersph_amd import txtio
 
 HOST_DIR = os.path.join(ROOT, "summersph_amd", "host")
 HOST_BIN = os.path.join(HOST_DIR, "run_sph_hip")
+HOST_BIN_V = os.path.join(HOST_DIR, "run_sph_hip_v")
 
 
-def _build():
-    if not os.path.exists(HOST_BIN):
+def _build(which=HOST_BIN):
+    if not os.path.exists(which):
         subprocess.run(["make", "-C", HOST_DIR], check=True, stdout=subprocess.DEVNULL)
-    return HOST_BIN
+    return which
 
 
 def test_host_builds_with_amdflang():
-    """CPU: the Fortran host compiles and links against the C ABI"""
-    assert os.path.exists(_build())
+    """CPU: both Fortran hosts compile and link against the C ABI"""
+    assert os.path.exists(_build()) and os.path.exists(_build(HOST_BIN_V))
 
 
 @pytest.mark.gpu
@@ -72,3 +73,30 @@ def test_fortran_host_reader_conventions(tmp_path):
     assert gas.shape == (49, 9) and sinks.shape == (1, 8)
     assert np.array_equal(gas[:, :8], np.delete(rows, 20, axis=0))
     assert np.array_equal(sinks[0, :6], rows[20, :6]) and sinks[0, 7] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["sph", "full"])
+def test_fortran_host_variable_h_trajectory(tmp_path, variant):
+    """the variable-h host (10-column ingest, parameters.txt, simulate with calc_smoothing) against the 5-step
+    trajectories of the real "SUMMER_SPH - Variable.f90"; 'full' = its simulate() as it is"""
+    g = load_golden("discv3000_traj")
+    gamma, eta, tol, maxlen, scale = (float(v) for v in g["params"])
+    icf = tmp_path / "ic10.txt"
+    txtio.write_ic(str(icf), g["ic"], header="x y z vx vy vz energy mass alpha smoothing")
+    pf = tmp_path / "parameters.txt"
+    pf.write_text("bounding_size max_depth theta gamma eta convergence_criteria max_length timestep_scale end_time\n"
+                  f"1500.0 1000 0.5 {gamma!r} {eta!r} {tol!r} {maxlen!r} {scale!r} 1000.0\n")
+    snap = tmp_path / "final.txt"
+    cmd = [_build(HOST_BIN_V), str(icf), str(pf), "5", str(snap)] + (["sph"] if variant == "sph" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Successfully read parameters" in r.stdout and "Successfully read" in r.stdout
+    dts = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("dt ")]
+    assert dts == list(g[variant + "_dt_seq"])
+    gas, sinks = txtio.read_snapshot_v(str(snap))      # 10 columns for gas, 8 for the sink row
+    p = f"{variant}_s5_"
+    assert gas.shape[0] == g[p + "x"].size and sinks.shape[0] == g[p + "sx"].size
+    for col, f in enumerate("x y z vx vy vz u m alpha h".split()):
+        assert rel_err(gas[:, col], g[p + f]) <= 1e-10, f
+    assert np.max(np.abs(sinks[:, 0] - g[p + "sx"])) <= 1e-11 and np.max(np.abs(sinks[:, 7] - g[p + "sm"])) <= 1e-14

@@ -21,11 +21,11 @@ def capi():
     return m
 
 
-def make_ctx(capi, g):
+def make_ctx(capi, g, **kw):
     gas, sinks = ic.split_rows(g["ic"])
     gamma, eta, tol, maxlen, scale = g["params"]
     ctx = capi.Context(device=0, variable=True, gamma=gamma, gamma_m1=gamma - 1.0, eta=eta, h_tol=tol,
-                       h_max_length=maxlen, dt_scale=scale)
+                       h_max_length=maxlen, dt_scale=scale, **kw)
     ctx.upload(gas)
     ctx.set_sinks(sinks)
     return ctx, gas, sinks
@@ -92,4 +92,20 @@ def test_disc_vs_oracle_larger(capi):
     assert ctx.next_dt(1e-2) == o.next_dt(1e-2)
     ctx.update_h(); o.update_h()
     assert rel_err(ctx.field("h"), o.h) <= 1e-12
+    ctx.close()
+
+
+def test_full_simulate_trajectory_vs_reference_fixture(capi):
+    """simulate() of the variable-h reference as it is: find_forces with the gas self-gravity (softening looked up
+    with the particle's own h), calc_smoothing, sink accretion ([V]'s L1-distance rule) and the boundary cull"""
+    g = load_golden("discv3000_traj")
+    ctx, gas, sinks = make_ctx(capi, g, flags=capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    dts, t = [1e-2], 0.0
+    for _ in range(5):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt)
+    assert dts == list(g["full_dt_seq"])
+    assert ctx.n == int(g["full_n_seq"][-1])
+    for f in "x y z vx vy vz u alpha h".split():
+        assert rel_err(ctx.field(f), g["full_s5_" + f]) <= 1e-10, f
     ctx.close()
