@@ -227,8 +227,16 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     az[64]), d_out[192] = its dt candidate: SPH_PARTIALS doubles, to be
  *                     all-gathered by the caller.
  * sph_apply_partials_dev  sink accelerations = sum over the nranks gathered blocks (rank order);
- *                     apply_dt != 0: t += dt, then [F]:855-858 with the minimum candidate.          */
+ *                     apply_dt != 0: t += dt, then [F]:855-858 with the minimum candidate.
+ * sph_set_boundary_boxes / sph_forces_part: forces in two launches so that the exchange of ghost fields overlaps
+ *                     the bulk of the work.  boxes = the other GPUs' bounding boxes {lo xyz, hi xyz} (every ghost lies
+ *                     inside them).  part 1: sink gravity + every wavefront whose 64 particles are all farther than
+ *                     2h from all boxes (they cannot have a ghost neighbour); part 2 (after the ghost fields arrived
+ *                     and sph_refresh_eos ran): the remaining wavefronts.  Together identical to sph_forces.
+ *                     Fixed-h contexts without self-gravity.                                              */
 #define SPH_PARTIALS 193
+int sph_set_boundary_boxes(sph_ctx *ctx, int32_t nbox, const double *boxes);
+int sph_forces_part(sph_ctx *ctx, int32_t part);
 int sph_set_stream(sph_ctx *ctx, void *hip_stream);
 int sph_reserve(sph_ctx *ctx, int64_t n_slots);
 int sph_owned_bbox(sph_ctx *ctx, double *lo_hi, double *d_lo_hi);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_pack_partials_dev",
-    "sph_apply_partials_dev",
+    "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
@@ -132,6 +132,8 @@ def load():
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.sph_pack_partials_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.sph_apply_partials_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.sph_set_boundary_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.sph_forces_part.argtypes = [C.c_void_p, C.c_int32]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
     _lib = lib
@@ -328,6 +330,14 @@ class Context:
 
     def apply_partials_dev(self, dev_ptr: int, nranks: int, stride: int, apply_dt: bool):
         self._ck(self.lib.sph_apply_partials_dev(self._h, C.c_void_p(dev_ptr), nranks, stride, 1 if apply_dt else 0))
+
+    def set_boundary_boxes(self, boxes: np.ndarray):
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        self._ck(self.lib.sph_set_boundary_boxes(self._h, boxes.shape[0], boxes.ctypes.data if boxes.size else None))
+
+    def forces_part(self, part: int):
+        """1: sink gravity + the wavefronts that cannot see a ghost; 2: the others (after refresh_eos)"""
+        self._ck(self.lib.sph_forces_part(self._h, part))
 
     def refresh_eos(self):
         self._ck(self.lib.sph_refresh_eos(self._h))

@@ -42,7 +42,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->drec); ctx_free(c, c->frec);
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
-    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail);
+    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class);
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
@@ -78,6 +78,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     API_TRY(ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list"));
     API_TRY(ctx_alloc(c, &c->ncount, (size_t)cap, "neighbour counts"));
     API_TRY(ctx_alloc(c, &c->wave_max, (size_t)c->nl_waves_cap, "wave max"));
+    API_TRY(ctx_alloc(c, &c->wave_class, (size_t)c->nl_waves_cap, "wave classes"));
     if (c->variable) {
         API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
@@ -176,6 +177,7 @@ int do_density(sph_ctx *c) {
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
         c->order_valid = true;
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
+        c->wave_class_valid = false; c->interior_done = false;
         if (c->variable) {
             { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
             { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
@@ -206,6 +208,28 @@ int do_forces(sph_ctx *c) {
     }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
     { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc) : launch_forces(c, pc))); }
+    c->force_passes++;
+    c->rates_valid = true;
+    return SPH_OK;
+}
+
+// forces in two parts (multi-GPU overlap): 1 = sink gravity + the waves that cannot see a ghost, while the ghost
+// fields are still travelling; 2 = the remaining waves, after sph_refresh_eos
+int do_forces_part(sph_ctx *c, int part) {
+    if (c->variable || c->gravity || c->tiled_eval) { c->err = "sph_forces_part: fixed-h contexts without self-gravity only"; return SPH_ERR_STATE; }
+    if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces_part: call sph_density first"; return SPH_ERR_STATE; }
+    const PairConst pc = make_pair_const(c);
+    if (part == 1) {
+        if (!c->wave_class_valid) { API_HIP(launch_classify_waves(c)); c->wave_class_valid = true; }
+        { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
+        { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc, 1)); }
+        c->interior_done = true;
+        c->rates_valid = false;
+        return SPH_OK;
+    }
+    if (!c->interior_done) { c->err = "sph_forces_part: part 2 before part 1"; return SPH_ERR_STATE; }
+    { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc, 2)); }
+    c->interior_done = false;
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -388,8 +412,8 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     int st = SPH_OK;
     auto fail = [&](int s) { sph_ctx_destroy(c); return s; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
-    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 256 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
-    std::memset(c->h_pinned, 0, 256 * sizeof(double));
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 640 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
+    std::memset(c->h_pinned, 0, 640 * sizeof(double));
     if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 16, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
@@ -435,7 +459,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    ctx_free(c, c->sel_count); ctx_free_ptr(c, c->sel_tmp);
+    ctx_free(c, c->sel_count); ctx_free_ptr(c, c->sel_tmp); ctx_free(c, c->bnd_boxes);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -765,6 +789,23 @@ int sph_replace_ghosts_dev(sph_ctx *c, int64_t count, const double *d_state) {
     if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
     return SPH_OK;
+}
+
+int sph_set_boundary_boxes(sph_ctx *c, int32_t nbox, const double *boxes) {
+    if (!c || nbox < 0 || nbox > MAX_SEL_BOXES || (nbox > 0 && !boxes)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    if (!c->bnd_boxes) API_TRY(ctx_alloc(c, &c->bnd_boxes, (size_t)6 * MAX_SEL_BOXES, "boundary boxes"));
+    for (int k = 0; k < 6 * nbox; k++) c->h_pinned[128 + k] = boxes[k];      // pinned staging: no host synchronisation
+    if (nbox > 0) API_HIP(hipMemcpyAsync(c->bnd_boxes, c->h_pinned + 128, (size_t)6 * nbox * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->n_bnd_boxes = nbox;
+    c->wave_class_valid = false;
+    return SPH_OK;
+}
+
+int sph_forces_part(sph_ctx *c, int32_t part) {
+    if (!c || (part != 1 && part != 2)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return do_forces_part(c, part);
 }
 
 int sph_set_dt(sph_ctx *c, double dt, double t) {

@@ -205,13 +205,21 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
                                                        double *__restrict__ ax, double *__restrict__ ay,
                                                        double *__restrict__ az, double *__restrict__ du,
                                                        double *__restrict__ dalpha, const int32_t *__restrict__ orig,
-                                                       int32_t n_owned) {
+                                                       int32_t n_owned, const int32_t *__restrict__ wave_class, int32_t want) {
     extern __shared__ double lds_dw[];
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (wave_class) {       // split evaluation (multi-GPU overlap): only the waves of class `want`; a block with none leaves
+        bool any = false;   // before it loads the table (workgroup-uniform: every thread looks at the block's waves)
+        const int64_t w0 = (i - threadIdx.x) >> 6;
+        for (int k = 0; k < BLOCK / 64; k++)
+            any |= ((w0 + k) << 6) < n && wave_class[w0 + k] == want;
+        if (!any) return;
+    }
     for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_dw[k] = dw_tab[k];
     __syncthreads();
 
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if ((i & ~(int64_t)63) >= n) return;
+    if (wave_class && wave_class[i >> 6] != want) return;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n && orig[i] < n_owned;
@@ -427,13 +435,41 @@ hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc) {
     return hipGetLastError();
 }
 
-hipError_t launch_forces(sph_ctx *c, const PairConst &pc) {
+// part 0: every wave.  part 1 / 2: only the waves of class 0 (interior: no lane within 2h of a ghost box) / class 1
+hipError_t launch_forces(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
     auto k = c->packed_list ? forces_kernel<PAIR_BLOCK, true> : forces_kernel<PAIR_BLOCK, false>;
     k<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
-        c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
+        c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
+        part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
+    return hipGetLastError();
+}
+
+// wave_class[w] = 1 if a lane of wave w lies within `reach` of one of the boxes (the other GPUs' bounding boxes: all
+// ghosts are inside them), else 0
+__global__ __launch_bounds__(256) void classify_waves(const double4 *__restrict__ drec, int64_t n, const double *__restrict__ boxes,
+                                                      int nbox, double reach, int32_t *__restrict__ wave_class) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool near = false;
+    if (i < n) {
+        const double4 p = drec[i];
+        for (int b = 0; b < nbox; b++) {
+            const double *q = boxes + 6 * b;
+            const double dx = fmax(fmax(q[0] - p.x, p.x - q[3]), 0.0), dy = fmax(fmax(q[1] - p.y, p.y - q[4]), 0.0),
+                         dz = fmax(fmax(q[2] - p.z, p.z - q[5]), 0.0);
+            near |= dx <= reach && dy <= reach && dz <= reach;
+        }
+    }
+    const bool any = __any(near);
+    if ((threadIdx.x & 63) == 0 && (i & ~(int64_t)63) < n) wave_class[i >> 6] = any ? 1 : 0;
+}
+
+hipError_t launch_classify_waves(sph_ctx *c) {
+    if (c->n == 0) return hipSuccess;
+    classify_waves<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(
+        reinterpret_cast<const double4 *>(c->drec), c->n, c->bnd_boxes, c->n_bnd_boxes, 2.0 * c->p.h * (1.0 + 1e-9), c->wave_class);
     return hipGetLastError();
 }
 

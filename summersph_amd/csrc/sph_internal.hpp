@@ -72,6 +72,9 @@ struct sph_ctx {
     int64_t *sel_count = nullptr;
     void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;
     int32_t sel_boxes = 0; int64_t sel_counts[64] = {};  // last sph_select_boxes
+    // split force evaluation (sph_forces_part): waves near the other GPUs' boxes wait for the ghost fields
+    int32_t *wave_class = nullptr; double *bnd_boxes = nullptr; int32_t n_bnd_boxes = 0;
+    bool wave_class_valid = false, interior_done = false;
     bool own_stream = true;                              // false: the caller's stream (sph_set_stream), *_dev calls do not synchronise
 
     // cell-sorted struct-of-arrays state + derived + rates (SPH_F_* order)
@@ -182,7 +185,8 @@ int grid_rebuild(sph_ctx *c);
 int nlist_build(sph_ctx *c);
 hipError_t launch_density(sph_ctx *c, const PairConst &pc);
 hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc);
-hipError_t launch_forces(sph_ctx *c, const PairConst &pc);
+hipError_t launch_forces(sph_ctx *c, const PairConst &pc, int part = 0);
+hipError_t launch_classify_waves(sph_ctx *c);
 hipError_t launch_sink_accel(sph_ctx *c, const PairConst &pc);
 hipError_t launch_kick(sph_ctx *c, double dt, bool dt_from_device);
 hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device);

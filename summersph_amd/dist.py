@@ -125,6 +125,15 @@ class HipBackend:
     def forces(self):
         self.ctx.forces()
 
+    def set_boundary_boxes(self, boxes):
+        self.ctx.set_boundary_boxes(boxes)
+
+    def forces_interior(self):
+        self.ctx.forces_part(1)
+
+    def forces_boundary(self):
+        self.ctx.forces_part(2)
+
     def set_dt(self, dt, t):
         self.ctx.set_dt(dt, t)
 
@@ -324,6 +333,10 @@ class DistSim:
                     self.send_idx[q] = ids
         cm = self._all_gather(torch.tensor(counts, dtype=torch.int64)).cpu()
         rc = [int(cm[q, self.rank]) for q in range(self.P)]
+        # every ghost I am about to receive lies inside its owner's box: particles farther than 2h from all of them
+        # cannot have a ghost neighbour (their forces do not wait for the ghost fields)
+        senders = [q for q in range(self.P) if rc[q] > 0]
+        be.set_boundary_boxes(boxes[senders] if senders else np.zeros((0, 6)))
         send = [be.gather(STATE, idx) if idx is not None else None for idx in self.send_idx]
         recv = self._p2p(send, rc, 9)
         first = self.n_owned
@@ -389,25 +402,28 @@ class DistSim:
                     self._exchange_ghosts()
             with self._phase("compute"):
                 be.density()
-            with self._phase("ghost_rho"):
-                self._refresh_ghost_fields(["rho"])
-            if self.P > 1:
-                with self._phase("compute"):
-                    be.refresh_eos()
+            pending, tag = (self._refresh_ghost_start(["rho"]) if self.P > 1 else None), "ghost_rho"
         else:
             # the density sum needs positions and masses only: it runs while the ghosts' v, u, alpha travel
             with self._phase("ghost_vel"):
                 pending = self._refresh_ghost_start(["vx", "vy", "vz", "u", "alpha"]) if self.vel_dirty else None
+            tag = "ghost_vel"
             with self._phase("compute"):
                 be.density()
-            with self._phase("ghost_vel"):
-                self._refresh_ghost_finish(pending)
-            if self.P > 1:
-                with self._phase("compute"):
-                    be.refresh_eos()
         self.pos_dirty = self.vel_dirty = False
-        with self._phase("compute"):
-            be.forces()
+        if self.P > 1:
+            # ... and so do the forces of the particles that cannot see a ghost; the rest follows once the ghost
+            # fields have arrived and the EOS of the ghosts is refreshed
+            with self._phase("compute"):
+                be.forces_interior()
+            with self._phase(tag):
+                self._refresh_ghost_finish(pending)
+            with self._phase("compute"):
+                be.refresh_eos()
+                be.forces_boundary()
+        else:
+            with self._phase("compute"):
+                be.forces()
         with self._phase("reduce"):
             self._reduce()
 

@@ -162,6 +162,16 @@ class OracleBackend:
                                  C.c_int(self.nq), _p(self.w), _p(self.dw), _p(f["ax"]), _p(f["ay"]), _p(f["az"]),
                                  _p(f["du"]), _p(f["dalpha"]), C.c_int(2))
 
+    # split evaluation: the oracle backend does everything in the second part (after the ghost fields arrived)
+    def set_boundary_boxes(self, boxes):
+        self.boundary_boxes = np.asarray(boxes)
+
+    def forces_interior(self):
+        pass
+
+    def forces_boundary(self):
+        self.forces()
+
     def kick(self):
         f, s, dt = self.f, self.s, self.dt
         orc.lib().orc_kick(C.c_int(self.n), _p(f["vx"]), _p(f["vy"]), _p(f["vz"]), _p(f["u"]), _p(f["alpha"]),

@@ -175,3 +175,41 @@ def test_context_on_callers_stream(capi, torch):
     assert np.array_equal(got[1], 2.0 * gas["x"][::7])
     assert np.array_equal(got[0], 2.0 * ctx.field("rho")[::7])
     ctx.close()
+
+
+def test_split_force_evaluation_is_bitwise_the_full_one(capi, torch):
+    """sph_forces_part 1 + 2 (interior wavefronts, then the ones near the other GPUs' boxes) == sph_forces"""
+    gas, sinks = _disc(30000, 9)
+    own, gh, cut = _split(gas)
+    both = np.concatenate([own, gh])
+    ctxs = []
+    for _ in range(2):
+        c = _upload(capi, torch, gas, both)
+        c.set_owned(own.size)
+        c.set_sinks(sinks)
+        c.density()
+        rho_g = torch.from_numpy(np.full((1, gh.size), 1.2e-4)).cuda()
+        torch.cuda.synchronize()
+        c.scatter_fields_dev(["rho"], own.size, gh.size, rho_g.data_ptr())
+        c.refresh_eos()
+        ctxs.append(c)
+    full, split = ctxs
+    full.forces()
+    with pytest.raises(capi.SphError):
+        split.forces_part(2)                                   # part 2 before part 1
+    gpos = np.stack([gas[k][gh] for k in "xyz"])
+    split.set_boundary_boxes(np.concatenate([gpos.min(1), gpos.max(1)])[None, :])
+    split.forces_part(1)
+    with pytest.raises(capi.SphError):
+        split.kick(0.01)                                       # rates are not complete yet
+    split.forces_part(2)
+    for f in ("ax", "ay", "az", "du", "dalpha"):
+        assert np.array_equal(split.field(f)[:own.size], full.field(f)[:own.size]), f
+    a, b = full.get_sinks(), split.get_sinks()
+    assert np.array_equal(a["ax"], b["ax"])
+    # no boxes at all: everything is interior, part 2 has nothing left to do but completes the evaluation
+    split.set_boundary_boxes(np.zeros((0, 6)))
+    split.forces_part(1); split.forces_part(2)
+    assert np.array_equal(split.field("ax")[:own.size], full.field("ax")[:own.size])
+    for c in ctxs:
+        c.close()
