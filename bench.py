@@ -48,11 +48,24 @@ FP64_PEAK_TFLOPS = 78.6    # vector fp64
 FLOPS_DENSITY_PAIR, FLOPS_FORCE_PAIR = 22, 75
 
 
+def usable_cores():
+    """cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of its host cores; more threads than that only oversubscribe)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(n_total, nngb, seconds_target=15.0):
     """CPU oracle on the host cores of this box, bounded sample (about seconds_target of CPU work)."""
     from oracle import orc
     from summersph_amd import ic
-    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
+    threads = max(1, min(orc.max_threads(), usable_cores()))
     # calibrate on a small disc of the same surface density, then size the sample
     rows = ic.keplerian_disc(20000, seed=1, nngb=nngb)
     gas, sinks = ic.split_rows(rows)
