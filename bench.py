@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--tile-eval", action="store_true", help="SPH_FLAG_LDS_TILE_EVAL: LDS-staged density/forces (A/B)")
     ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
                     help="headline workload; variable is single-GPU only")
+    ap.add_argument("--self-gravity", action="store_true", help="SPH_FLAG_SELF_GRAVITY in the headline run (NOT the "
+                    "default workload): Barnes-Hut gas self-gravity; with --gpus > 1 every rank builds the replicated tree")
     ap.add_argument("--dist-profile", action="store_true", help="N>1: synchronise at phase boundaries and report wall "
                     "time per phase of the distributed step (perturbs the headline value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -182,7 +184,7 @@ def main():
         raise SystemExit("the variable-h path is single-GPU this round (its octree leaf boxes need the global particle "
                          "set); use --mode fixed for --gpus > 1")
     flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
-        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0)
+        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0)
 
     # ---- headline workload -----------------------------------------------------------------------
     sim = None
@@ -245,7 +247,8 @@ def main():
         wl = (f"uniform Keplerian disc, {args.n} gas particles + 1 sink per GPU, "
               + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
                  if variable else "fixed h=2.5 ([F] path, BASELINE configs[1] shape at the metric's N=1e6), ")
-              + f"mean {st.nlist_mean:.1f} list entries per particle, 2 density + 2 force passes per step")
+              + f"mean {st.nlist_mean:.1f} list entries per particle, 2 density + 2 force passes per step"
+              + (", Barnes-Hut gas self-gravity (theta 0.5)" if args.self_gravity else ""))
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

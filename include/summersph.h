@@ -233,8 +233,15 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     inside them).  part 1: sink gravity + every wavefront whose 64 particles are all farther than
  *                     2h from all boxes (they cannot have a ghost neighbour); part 2 (after the ghost fields arrived
  *                     and sph_refresh_eos ran): the remaining wavefronts.  Together identical to sph_forces.
- *                     Fixed-h contexts without self-gravity.                                              */
+ *                     Fixed-h contexts without self-gravity.
+ * sph_set_gravity_sources_dev  self-gravity from a particle set other than the context's own: n_src records
+ *                     {x, y, z, m} in device memory (caller-owned, must stay valid until replaced) and their bounding
+ *                     box {min xyz, max xyz} (host).  The Barnes-Hut tree is then built over these sources -- with
+ *                     every GPU's particles all-gathered into them it is the SAME tree on every GPU as the single
+ *                     tree of the undecomposed run -- and walked for the context's owned particles.  n_src = 0: back
+ *                     to the context's own particles.                                                        */
 #define SPH_PARTIALS 193
+int sph_set_gravity_sources_dev(sph_ctx *ctx, int64_t n_src, const double *d_xyzm, const double *lo_hi);
 int sph_set_boundary_boxes(sph_ctx *ctx, int32_t nbox, const double *boxes);
 int sph_forces_part(sph_ctx *ctx, int32_t part);
 int sph_set_stream(sph_ctx *ctx, void *hip_stream);

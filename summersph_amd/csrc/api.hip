@@ -46,9 +46,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
-    ctx_free(c, c->g_left); ctx_free(c, c->g_right); ctx_free(c, c->g_parent); ctx_free(c, c->g_leaf_parent);
-    ctx_free(c, c->g_prefix); ctx_free(c, c->g_flag); ctx_free(c, c->g_slot); ctx_free(c, c->g_lvl); ctx_free(c, c->g_rope);
-    ctx_free(c, c->g_leaf_rope); ctx_free(c, c->g_sum); ctx_free(c, c->g_seg); ctx_free(c, c->g_wrec); ctx_free(c, c->g_leaf_of); ctx_free(c, c->g_leafA); ctx_free(c, c->g_walkB); ctx_free(c, c->g_leafB);
+    gravity_free(c);                                     // tree arrays are (re)allocated by the next tree build
     c->msort_tmp_bytes = 0;
     c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
 }
@@ -94,15 +92,6 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
         API_HIP(varh_sort_tmp_bytes(cap, &mt));
         c->msort_tmp_bytes = mt;
         API_TRY(ctx_alloc_bytes(c, &c->msort_tmp, mt ? mt : 1, "octree sort scratch"));
-    }
-    if (c->gravity) {
-        API_TRY(ctx_alloc(c, &c->g_left, (size_t)cap, "tree left")); API_TRY(ctx_alloc(c, &c->g_right, (size_t)cap, "tree right"));
-        API_TRY(ctx_alloc(c, &c->g_parent, (size_t)cap, "tree parent")); API_TRY(ctx_alloc(c, &c->g_leaf_parent, (size_t)cap, "leaf parent"));
-        API_TRY(ctx_alloc(c, &c->g_prefix, (size_t)cap, "tree prefix")); API_TRY(ctx_alloc(c, &c->g_flag, (size_t)cap, "tree flags"));
-        API_TRY(ctx_alloc(c, &c->g_slot, (size_t)cap, "leaf slots")); API_TRY(ctx_alloc(c, &c->g_lvl, (size_t)cap, "tree levels"));
-        API_TRY(ctx_alloc(c, &c->g_rope, (size_t)cap, "tree ropes")); API_TRY(ctx_alloc(c, &c->g_leaf_rope, (size_t)cap, "leaf ropes"));
-        API_TRY(ctx_alloc(c, &c->g_sum, (size_t)cap * 4, "node sums")); API_TRY(ctx_alloc(c, &c->g_leaf_of, (size_t)cap, "slot -> leaf")); API_TRY(ctx_alloc(c, &c->g_wrec, (size_t)cap * 16, "wave walk records")); API_TRY(ctx_alloc(c, &c->g_seg, ((size_t)cap + 64) * 4, "segment tree")); API_TRY(ctx_alloc(c, &c->g_leafA, (size_t)cap * 4, "leaf records"));
-        API_TRY(ctx_alloc(c, &c->g_walkB, (size_t)cap * 4, "walk records")); API_TRY(ctx_alloc(c, &c->g_leafB, (size_t)cap * 2, "leaf walk records"));
     }
     c->cap = cap;
     return SPH_OK;
@@ -806,6 +795,17 @@ int sph_forces_part(sph_ctx *c, int32_t part) {
     if (!c || (part != 1 && part != 2)) return SPH_ERR_ARG;
     DeviceGuard g(c->device);
     return do_forces_part(c, part);
+}
+
+int sph_set_gravity_sources_dev(sph_ctx *c, int64_t n_src, const double *d_xyzm, const double *lo_hi) {
+    if (!c || n_src < 0 || (n_src > 0 && (!d_xyzm || !lo_hi))) return SPH_ERR_ARG;
+    if (!c->gravity) { c->err = "sph_set_gravity_sources_dev: context without SPH_FLAG_SELF_GRAVITY"; return SPH_ERR_STATE; }
+    c->gx_src = n_src > 0 ? d_xyzm : nullptr;
+    c->gx_n = n_src;
+    for (int a = 0; a < 6; a++) c->gx_box[a] = n_src > 0 ? lo_hi[a] : 0.0;
+    c->tree_valid = false;
+    c->rates_valid = false;
+    return SPH_OK;
 }
 
 int sph_set_dt(sph_ctx *c, double dt, double t) {

@@ -332,24 +332,28 @@ __global__ __launch_bounds__(GB) void node_wave_records(int n, TreeArrays t, Roo
 // accepted the node sleeps until the walk leaves that subtree -- it wakes at the node's rope, which every exit
 // from the subtree reaches.  Each lane therefore accumulates exactly the contributions of its own walk, in the same
 // order as grav_walk (kept as the per-lane reference implementation, SPH_GRAV_WAVE=0).
-__global__ __launch_bounds__(GB) void grav_walk_wave(int n, const WalkRec *__restrict__ rec, const double4 *__restrict__ leafA,
-                                                     const int32_t *__restrict__ leaf_of, const double *__restrict__ hvar,
+__global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRec *__restrict__ rec, const double4 *__restrict__ leafA,
+                                                     const double4 *__restrict__ drec, const int32_t *__restrict__ leaf_of,
+                                                     const double *__restrict__ hvar,
                                                      double hfix, double soft2, double theta, double G,
                                                      const double *__restrict__ gt, int nq, double dq, double *__restrict__ ax,
                                                      double *__restrict__ ay, double *__restrict__ az, const int32_t *__restrict__ orig,
                                                      int32_t n_owned, unsigned long long *__restrict__ stats) {
+    // nt targets (the context's cell-sorted slots); the tree has n leaves: the same particles (leaf_of: slot -> leaf),
+    // or an external source set (multi-GPU: every GPU's particles; leaf_of == nullptr).  A target's own leaf needs no
+    // special case then: its direction is exactly 0 and it adds 0 * f.
     const int i = xcd_chunk(blockIdx.x, gridDim.x) * GB + threadIdx.x;       // target: cell-sorted slot
-    const int self = i < n ? i : n - 1;
-    const bool live = i < n && orig[self] < n_owned;
-    const int j = leaf_of[self];                                              // its leaf (key order)
-    const double4 p = leafA[j];
+    const int self = i < nt ? i : nt - 1;
+    const bool live = i < nt && orig[self] < n_owned;
+    const int j = leaf_of ? leaf_of[self] : -1;                               // its leaf (key order)
+    const double4 p = leaf_of ? leafA[j] : drec[self];
     const double hp = hvar ? hvar[self] : hfix;
     const double inv_hp = 1.0 / hp, inv_dq = 1.0 / dq, theta2 = theta * theta, rsoft2 = 4.0 * hp * hp;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     bool active = live;                       // the root is an octree node by construction
     int resume = END;
     int node = n >= 2 ? 0 : END;
-    const int own = n - 1 + j;                // unified index of the target's own leaf
+    const int own = leaf_of ? n - 1 + j : END;    // unified index of the target's own leaf
     unsigned visits = 0, sums = 0;
     while (node != END) {
         node = __builtin_amdgcn_readfirstlane(node);
@@ -419,29 +423,66 @@ static TreeArrays tree_arrays(sph_ctx *c) {
     return t;
 }
 
-// builds the tree for the current (cell-sorted) positions
+void gravity_free(sph_ctx *c) {
+    ctx_free(c, c->g_left); ctx_free(c, c->g_right); ctx_free(c, c->g_parent); ctx_free(c, c->g_leaf_parent);
+    ctx_free(c, c->g_prefix); ctx_free(c, c->g_flag); ctx_free(c, c->g_slot); ctx_free(c, c->g_lvl); ctx_free(c, c->g_rope);
+    ctx_free(c, c->g_leaf_rope); ctx_free(c, c->g_sum); ctx_free(c, c->g_seg); ctx_free(c, c->g_wrec); ctx_free(c, c->g_leaf_of);
+    ctx_free(c, c->g_leafA); ctx_free(c, c->g_walkB); ctx_free(c, c->g_leafB);
+    ctx_free(c, c->g_keys); ctx_free(c, c->g_keys_alt); ctx_free(c, c->g_vals); ctx_free(c, c->g_vals_alt);
+    ctx_free_ptr(c, c->g_sort_tmp); c->g_sort_tmp = nullptr; c->g_sort_tmp_bytes = 0;
+    c->g_cap = 0;
+}
+
+// tree arrays for `need` leaves (the context's slots, or an external source set that may be much larger)
+static int gravity_reserve(sph_ctx *c, int64_t need) {
+    if (need <= c->g_cap) return SPH_OK;
+    gravity_free(c);
+    const size_t cap = (size_t)(need + need / 16 + 64);
+#define G_ALLOC(p, cnt, what) do { int _s = ctx_alloc(c, &(p), (cnt), what); if (_s != SPH_OK) return _s; } while (0)
+    G_ALLOC(c->g_left, cap, "tree left"); G_ALLOC(c->g_right, cap, "tree right"); G_ALLOC(c->g_parent, cap, "tree parent");
+    G_ALLOC(c->g_leaf_parent, cap, "leaf parent"); G_ALLOC(c->g_prefix, cap, "tree prefix"); G_ALLOC(c->g_flag, cap, "range ends");
+    G_ALLOC(c->g_slot, cap, "leaf slots"); G_ALLOC(c->g_lvl, cap, "tree levels"); G_ALLOC(c->g_rope, cap, "tree ropes");
+    G_ALLOC(c->g_leaf_rope, cap, "leaf ropes"); G_ALLOC(c->g_sum, cap * 4, "node sums"); G_ALLOC(c->g_seg, (cap + 64) * 4, "segment tree");
+    G_ALLOC(c->g_wrec, cap * 16, "wave walk records"); G_ALLOC(c->g_leaf_of, cap, "slot -> leaf"); G_ALLOC(c->g_leafA, cap * 4, "leaf records");
+    G_ALLOC(c->g_walkB, cap * 4, "walk records"); G_ALLOC(c->g_leafB, cap * 2, "leaf walk records");
+    G_ALLOC(c->g_keys, cap, "tree keys"); G_ALLOC(c->g_keys_alt, cap, "tree keys (alt)");
+    G_ALLOC(c->g_vals, cap, "tree vals"); G_ALLOC(c->g_vals_alt, cap, "tree vals (alt)");
+#undef G_ALLOC
+    size_t tmp = 0;
+    GR_CHECK2(grav_sort_tmp_bytes((int64_t)cap, &tmp));
+    if (ctx_alloc_bytes(c, &c->g_sort_tmp, tmp ? tmp : 1, "tree sort scratch") != SPH_OK) return SPH_ERR_NOMEM;
+    c->g_sort_tmp_bytes = tmp;
+    c->g_cap = (int64_t)cap;
+    return SPH_OK;
+}
+
+// builds the tree over the context's own particles (current cell-sorted positions) or over the external source set
 int gravity_tree_build(sph_ctx *c) {
-    const int64_t n = c->n;
+    const bool ext = c->gx_src != nullptr;
+    const int64_t n = ext ? c->gx_n : c->n;
     if (n == 0) return SPH_OK;
+    if (n > 2000000000LL) { c->err = "gravity: more than 2e9 sources"; return SPH_ERR_ARG; }
+    { const int st = gravity_reserve(c, ext ? n : std::max(c->cap, n)); if (st != SPH_OK) return st; }
+    const double *bb = ext ? c->gx_box : c->bbox;
     RootBox rb;
     double size = 0.0;
     for (int a = 0; a < 3; a++) {
-        rb.c[a] = (c->bbox[3 + a] + c->bbox[a]) / 2.0;                  // [F]:803-805
-        size = std::max(size, c->bbox[3 + a] - c->bbox[a]);             // [F]:806-808
+        rb.c[a] = (bb[3 + a] + bb[a]) / 2.0;                            // [F]:803-805
+        size = std::max(size, bb[3 + a] - bb[a]);                       // [F]:806-808
     }
     rb.size = size;
     for (int a = 0; a < 3; a++) c->root_box[a] = rb.c[a];
     c->root_box[3] = size;
     const unsigned gb = (unsigned)((n + GB - 1) / GB);
-    const double4 *drec = reinterpret_cast<const double4 *>(c->drec);
-    grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->mkeys, c->mvals);
+    const double4 *drec = reinterpret_cast<const double4 *>(ext ? c->gx_src : c->drec);
+    grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->g_keys, c->g_vals);
     GR_CHECK2(hipGetLastError());
-    size_t tmp = c->msort_tmp_bytes;
-    GR_CHECK2(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+    size_t tmp = c->g_sort_tmp_bytes;
+    GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
     TreeArrays t = tree_arrays(c);
-    leaf_data<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->mvals_alt, drec, (int)n, t);
+    leaf_data<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->g_vals_alt, drec, (int)n, t);
     if (n >= 2) {
-        radix_tree<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->mkeys_alt, (int)n, t);
+        radix_tree<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->g_keys_alt, (int)n, t);
         SegLevels sl{};
         sl.cnt[0] = n; sl.off[0] = 0; sl.levels = 1;
         int64_t off = 0;
@@ -463,23 +504,26 @@ int gravity_tree_build(sph_ctx *c) {
 }
 
 hipError_t launch_gravity(sph_ctx *c) {
-    const int64_t n = c->n;
-    if (n == 0) return hipSuccess;
+    const bool ext = c->gx_src != nullptr;
+    const int64_t nt = c->n;                     // targets: the context's slots
+    const int64_t n = ext ? c->gx_n : c->n;      // leaves of the tree
+    if (nt == 0 || n == 0) return hipSuccess;
     RootBox rb;
     for (int a = 0; a < 3; a++) rb.c[a] = c->root_box[a];
     rb.size = c->root_box[3];
     const double soft2 = 0.001 * 2.5;                                   // 0.001_dp*smoothing, MODULE constant ([F]:275, [V]:296)
     static int wave_walk = -1;
     if (wave_walk < 0) { const char *e = getenv("SPH_GRAV_WAVE"); wave_walk = e ? atoi(e) : 1; }
-    if (wave_walk) {
+    if (wave_walk || ext) {
         TreeArrays ta = tree_arrays(c);
         unsigned long long *stats = nullptr;
         if (wave_walk == 2) {                                           // debug: visit / contribution counts
             if (hipMalloc(reinterpret_cast<void **>(&stats), 16) != hipSuccess) return hipGetLastError();
             (void)hipMemsetAsync(stats, 0, 16, c->stream);
         }
-        grav_walk_wave<<<dim3((unsigned)((n + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
-            (int)n, reinterpret_cast<const WalkRec *>(c->g_wrec), ta.leafA, c->g_leaf_of, c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
+        grav_walk_wave<<<dim3((unsigned)((nt + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
+            (int)nt, (int)n, reinterpret_cast<const WalkRec *>(c->g_wrec), ta.leafA, reinterpret_cast<const double4 *>(c->drec),
+            ext ? nullptr : c->g_leaf_of, c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
             c->p.theta, c->p.G, c->grav_tab, c->p.nq, 2.0 / c->p.nq, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
             (int32_t)c->n_owned, stats);
         if (stats) {

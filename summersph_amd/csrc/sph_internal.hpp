@@ -114,6 +114,11 @@ struct sph_ctx {
     double *g_seg = nullptr;                         // segment tree of leaf moments: 4 doubles x (cap + 64)
     int32_t *g_walkB = nullptr, *g_leafB = nullptr;  // int4 per node, int2 per leaf: packed walk pointers
     double *grav_tab = nullptr;                      // softening table, [F]:81-101
+    uint64_t *g_keys = nullptr, *g_keys_alt = nullptr; uint32_t *g_vals = nullptr, *g_vals_alt = nullptr;
+    void *g_sort_tmp = nullptr; size_t g_sort_tmp_bytes = 0;
+    int64_t g_cap = 0;                               // leaves the tree arrays hold
+    // external gravity sources (multi-GPU: the particles of every GPU), caller-owned {x,y,z,m} records + their bounding box
+    const double *gx_src = nullptr; int64_t gx_n = 0; double gx_box[6] = {0, 0, 0, 0, 0, 0};
 
     // grid
     sph::GridDesc grid{};
@@ -211,6 +216,7 @@ hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
 // self-gravity (gravity.hip)
 hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
 int gravity_tree_build(sph_ctx *c);
+void gravity_free(sph_ctx *c);
 hipError_t launch_gravity(sph_ctx *c);
 // accretion + boundary cull (accrete.hip)
 int accrete_and_cull(sph_ctx *c, int64_t *removed);

@@ -21,6 +21,9 @@ the GPU context; per step (= the reference's loop body, [F]:889-916) the ranks e
     7. all-gather [193 doubles/rank]: partial sink accelerations
   kick; the local dt candidate stays on the device until 2. of the next step.
 
+With SPH_FLAG_SELF_GRAVITY every rank additionally all-gathers {x, y, z, m} of all particles after a drift and builds
+the same Barnes-Hut tree as the undecomposed run (replicated build, shared walk; `_gravity_sources`).
+
 Every `migrate_every` steps the particles that left their slab change owner first (the ghost
 selection uses bounding boxes, not slab edges, so ownership only matters for load balance).
 
@@ -128,6 +131,15 @@ class HipBackend:
     def set_boundary_boxes(self, boxes):
         self.ctx.set_boundary_boxes(boxes)
 
+    @property
+    def gravity(self) -> bool:
+        return bool(self.ctx.params.flags & self.capi.FLAG_SELF_GRAVITY)
+
+    def set_gravity_sources(self, src: torch.Tensor, lo_hi: np.ndarray):
+        """src: [N, 4] records {x, y, z, m} of EVERY rank's particles; kept alive here until replaced"""
+        self._grav_src = src.contiguous()
+        self.ctx.set_gravity_sources_dev(int(self._grav_src.shape[0]), self._grav_src.data_ptr(), lo_hi)
+
     def forces_interior(self):
         self.ctx.forces_part(1)
 
@@ -204,6 +216,9 @@ class DistSim:
         self.ghost_count = [0] * self.P
         self.t = 0.0
         self.stats = {"ghosts": 0, "migrated": 0, "exchanges": 0, "migrations": 0}
+        self.gravity = bool(getattr(backend, "gravity", False))     # Barnes-Hut self-gravity: replicated tree (below)
+        self.counts_all = None    # owned particles of every rank (changes with migrations only)
+        self.boxes = None         # every rank's owned bounding box at the last ghost exchange (host)
         self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
         self.phase_s = {}
         self._gather_into = True  # all_gather_into_tensor until the backend refuses it
@@ -312,6 +327,7 @@ class DistSim:
         """steps 3-5 of the module docstring: who needs which of my particles, ship them, swap them in"""
         be = self.be
         boxes = self._all_gather(be.owned_bbox()).cpu().numpy()     # [P, 6] on the host
+        self.boxes = boxes
         r = 2.0 * self.h * (1.0 + 1e-9)
         me_lo, me_hi = boxes[self.rank, :3], boxes[self.rank, 3:]
         mine_ok = bool(np.all(np.isfinite(boxes[self.rank])))
@@ -355,6 +371,24 @@ class DistSim:
         self.stats["ghosts"] = int(ghosts.shape[1])
         be.replace_ghosts(ghosts)
 
+    def _gravity_sources(self):
+        """Self-gravity is long range: every rank gets {x, y, z, m} of ALL particles (one all-gather, padded to the
+        largest rank) and builds the same Barnes-Hut tree as the undecomposed run would -- same particles, same root
+        box, hence the same nodes and the same accepted set for every target -- and walks it for its own particles.
+        The tree build is replicated work; the walk, which dominates, is shared."""
+        be = self.be
+        if self.counts_all is None:
+            self.counts_all = [int(v) for v in self._all_gather(torch.tensor([self.n_owned], dtype=torch.int64)).cpu()[:, 0]]
+        mine = be.gather(["x", "y", "z", "m"], None, self.n_owned)            # [4, n_owned]
+        maxn = max(self.counts_all)
+        buf = torch.zeros((4, maxn), dtype=torch.float64, device=self.dev)
+        buf[:, :self.n_owned] = mine
+        allb = self._all_gather(buf.view(-1)).to(self.dev).view(self.P, 4, maxn)
+        src = torch.cat([allb[r, :, :self.counts_all[r]].T for r in range(self.P)], dim=0).contiguous()   # [N, 4]
+        ok = [r for r in range(self.P) if self.counts_all[r] > 0]
+        lo_hi = np.concatenate([self.boxes[ok, :3].min(0), self.boxes[ok, 3:].max(0)])
+        be.set_gravity_sources(src, lo_hi)
+
     def _refresh_ghost_start(self, names):
         """ship the listed fields of the particles my peers hold as ghosts (posts the messages)"""
         if self.P == 1:
@@ -397,9 +431,13 @@ class DistSim:
                 with self._phase("upload"):
                     be.upload(self.owned)
                 self.in_backend = True
+                self.counts_all = None
             if self.P > 1:
                 with self._phase("ghost_exchange"):
                     self._exchange_ghosts()
+                if self.gravity:
+                    with self._phase("gravity_sources"):
+                        self._gravity_sources()
             with self._phase("compute"):
                 be.density()
             pending, tag = (self._refresh_ghost_start(["rho"]) if self.P > 1 else None), "ghost_rho"
@@ -411,7 +449,7 @@ class DistSim:
             with self._phase("compute"):
                 be.density()
         self.pos_dirty = self.vel_dirty = False
-        if self.P > 1:
+        if self.P > 1 and not self.gravity:
             # ... and so do the forces of the particles that cannot see a ghost; the rest follows once the ghost
             # fields have arrived and the EOS of the ghosts is refreshed
             with self._phase("compute"):
@@ -421,6 +459,12 @@ class DistSim:
             with self._phase("compute"):
                 be.refresh_eos()
                 be.forces_boundary()
+        elif self.P > 1:
+            with self._phase(tag):
+                self._refresh_ghost_finish(pending)
+            with self._phase("compute"):
+                be.refresh_eos()
+                be.forces()
         else:
             with self._phase("compute"):
                 be.forces()

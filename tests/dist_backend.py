@@ -19,7 +19,9 @@ def _p(a):
 class OracleBackend:
     STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
 
-    def __init__(self, h=2.5, nq=5000):
+    def __init__(self, h=2.5, nq=5000, gravity=False):
+        self.gravity = gravity
+        self.gtree = None
         self.device = torch.device("cpu")
         self.h, self.nq = h, nq
         self.w, self.dw, _ = orc.tables(nq)
@@ -157,10 +159,19 @@ class OracleBackend:
                     for k, a in enumerate(("ax", "ay", "az")):
                         s[a][i] += s["m"][j] * w[k]
                         s[a][j] -= s["m"][i] * w[k]
+        if self.gravity:
+            from oracle import orc_grav
+            tree = self.gtree if self.gtree is not None else orc_grav.Tree(f["x"], f["y"], f["z"], f["m"])
+            orc_grav.gravity(tree, f["x"], f["y"], f["z"], f["ax"], f["ay"], f["az"], h=self.h, nq=self.nq)
         orc.lib().orc_sph_forces(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["vx"]), _p(f["vy"]), _p(f["vz"]),
                                  _p(f["m"]), _p(f["rho"]), _p(f["P"]), _p(f["c"]), _p(f["alpha"]), C.c_double(self.h),
                                  C.c_int(self.nq), _p(self.w), _p(self.dw), _p(f["ax"]), _p(f["ay"]), _p(f["az"]),
                                  _p(f["du"]), _p(f["dalpha"]), C.c_int(2))
+
+    def set_gravity_sources(self, src, lo_hi):
+        from oracle import orc_grav
+        s = src.cpu().numpy()
+        self.gtree = orc_grav.Tree(*[np.ascontiguousarray(s[:, k]) for k in range(4)])   # root box = bbox of the sources
 
     # split evaluation: the oracle backend does everything in the second part (after the ghost fields arrived)
     def set_boundary_boxes(self, boxes):

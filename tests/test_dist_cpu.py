@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nsteps, outdir, ic_rows, migrate_every, chunk):
+def _worker(rank, world, port, nsteps, outdir, ic_rows, migrate_every, chunk, gravity=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -36,7 +36,7 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows, migrate_every, chunk):
     sel = owner == rank
     mine = {k: v[sel] for k, v in gas.items()}
     mine["gid"] = np.nonzero(sel)[0]
-    sim = DistSim(OracleBackend(), mine, sinks, bounds, migrate_every=migrate_every)
+    sim = DistSim(OracleBackend(gravity=gravity), mine, sinks, bounds, migrate_every=migrate_every)
     dts = [1e-2]
     for _ in range(0, nsteps, chunk):       # chunk > 1: the dt reduction rides on the next step's exchange
         dts.append(sim.run(chunk, dts[-1]))
@@ -48,8 +48,8 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows, migrate_every, chunk):
     dist.destroy_process_group()
 
 
-def _run(world, nsteps, rows, tmp_path, migrate_every=8, chunk=1):
-    mp.spawn(_worker, args=(world, _free_port(), nsteps, str(tmp_path), rows, migrate_every, chunk), nprocs=world, join=True)
+def _run(world, nsteps, rows, tmp_path, migrate_every=8, chunk=1, gravity=False):
+    mp.spawn(_worker, args=(world, _free_port(), nsteps, str(tmp_path), rows, migrate_every, chunk, gravity), nprocs=world, join=True)
     parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(world)]
     gid = np.concatenate([p["gid"] for p in parts])
     assert np.array_equal(np.sort(gid), np.arange(gid.size))          # every particle owned exactly once
@@ -89,3 +89,14 @@ def test_migration_happens_and_is_lossless(tmp_path):
     assert list(parts[0]["dts"]) == dts
     for f in FIELDS:
         assert rel_err(merged[f], getattr(o, f)) <= 1e-11, f
+
+
+def test_self_gravity_with_replicated_tree_vs_reference_fixture(tmp_path):
+    """find_forces with the Barnes-Hut term on 2 ranks: every rank builds the tree of ALL particles (all-gathered
+    sources) and walks it for its own; the result is the reference's full trajectory (no accretion happens in it)"""
+    g = load_golden("disc3000_traj")
+    parts, merged = _run(2, 5, g["ic"], tmp_path, gravity=True, migrate_every=2)
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+    for f in FIELDS:
+        assert rel_err(merged[f], g["full_s5_" + f]) <= 1e-11, f

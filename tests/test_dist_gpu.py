@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nsteps, outdir, ic_rows):
+def _worker(rank, world, port, nsteps, outdir, ic_rows, flags=0):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -34,7 +34,7 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows):
     sel = owner == rank
     mine = {k: v[sel] for k, v in gas.items()}
     mine["gid"] = np.nonzero(sel)[0]
-    sim = DistSim(HipBackend(0), mine, sinks, bounds, comm_device="cpu")
+    sim = DistSim(HipBackend(0, flags=flags), mine, sinks, bounds, comm_device="cpu", migrate_every=2)
     dts = [1e-2]
     for _ in range(nsteps):
         dts.append(sim.step(dts[-1]))
@@ -61,3 +61,17 @@ def test_hip_ghost_path_matches_reference_fixture(tmp_path, world):
     for f in FIELDS:
         merged = np.concatenate([p[f] for p in parts])[order]
         assert rel_err(merged, g["sph_s5_" + f]) <= 1e-11, f
+
+
+def test_hip_self_gravity_replicated_tree(tmp_path):
+    """SPH_FLAG_SELF_GRAVITY on 2 ranks: all-gathered sources, the same tree on both GPUs contexts, walk of the owned
+    particles -- against the real reference's full find_forces trajectory"""
+    g = load_golden("disc3000_traj")
+    mp.spawn(_worker, args=(2, _free_port(), 5, str(tmp_path), g["ic"], 16), nprocs=2, join=True)     # 16 = SELF_GRAVITY
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+    for f in FIELDS:
+        merged = np.concatenate([p[f] for p in parts])[order]
+        assert rel_err(merged, g["full_s5_" + f]) <= 1e-11, f
