@@ -110,9 +110,10 @@ def stream_copy_gbs(torch, device, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
-def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags):
+def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags, ring=False):
     """one context on `device` with the workload uploaded from device memory"""
-    rows = ic.keplerian_disc_var(n, seed=303) if variable else ic.keplerian_disc(n, seed=202, nngb=nngb)
+    rows = ic.keplerian_disc_var(n, seed=303) if variable else (
+        ic.thin_ring(n, seed=404) if ring else ic.keplerian_disc(n, seed=202, nngb=nngb))
     gas, sinks = ic.split_rows(rows)
     ctx = capi.Context(device=device, variable=True) if variable else capi.Context(device=device, flags=flags)
     dev = [torch.from_numpy(gas[k]).to(f"cuda:{device}") for k in "x y z vx vy vz u m alpha".split()]
@@ -152,6 +153,8 @@ def main():
     ap.add_argument("--tile-eval", action="store_true", help="SPH_FLAG_LDS_TILE_EVAL: LDS-staged density/forces (A/B)")
     ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
                     help="headline workload; variable is single-GPU only")
+    ap.add_argument("--ic", default="disc", choices=["disc", "ring"], help="fixed-h workload: the uniform disc (headline) or "
+                    "BASELINE configs[3]'s thin ring r ~ N(r0, 0.05 r0) (artificial viscosity at work)")
     ap.add_argument("--self-gravity", action="store_true", help="SPH_FLAG_SELF_GRAVITY in the headline run (NOT the "
                     "default workload): Barnes-Hut gas self-gravity; with --gpus > 1 every rank builds the replicated tree")
     ap.add_argument("--dist-profile", action="store_true", help="N>1: synchronise at phase boundaries and report wall "
@@ -189,14 +192,15 @@ def main():
     # ---- headline workload -----------------------------------------------------------------------
     sim = None
     if world == 1:
-        ctx = make_single_ctx(capi, ic, torch, variable, args.n, args.nngb, local_rank, flags)
+        ctx = make_single_ctx(capi, ic, torch, variable, args.n, args.nngb, local_rank, flags, ring=args.ic == "ring")
         elapsed, dt = timed_run(ctx, torch, args.steps, args.warmup)
         n_max = [args.n, 0]
     else:
         # weak scaling: the disc holds n x world particles (same surface density, larger radius); every rank
         # owns one equal-count x-slab of it
         from summersph_amd.dist import DistSim, HipBackend, slab_bounds
-        rows = ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb)
+        rows = (ic.thin_ring(args.n * world, seed=404) if args.ic == "ring"
+                else ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb))
         gas, sinks = ic.split_rows(rows)
         bounds = slab_bounds(gas["x"], world)
         sel = np.searchsorted(bounds, gas["x"], side="right") == rank
@@ -244,7 +248,8 @@ def main():
             rec = json.load(open(tf))
             if rec.get("workload_particles") == args.n:
                 traffic = rec["traffic_bytes_per_launch"]
-        wl = (f"uniform Keplerian disc, {args.n} gas particles + 1 sink per GPU, "
+        wl = ((f"thin Keplerian ring (r ~ N(r0, 0.05 r0)), " if args.ic == "ring" and not variable else "uniform Keplerian disc, ")
+              + f"{args.n} gas particles + 1 sink per GPU, "
               + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
                  if variable else "fixed h=2.5 ([F] path, BASELINE configs[1] shape at the metric's N=1e6), ")
               + f"mean {st.nlist_mean:.1f} list entries per particle, 2 density + 2 force passes per step"
@@ -277,7 +282,7 @@ def main():
             out["dist_phase_ms_per_step_rank0"] = {k: 1e3 * v / args.steps for k, v in sim.phase_s.items()}
             out["dist_stats_rank0"] = dict(sim.stats)
         ctx.close()
-        if world == 1 and not variable and not args.no_variable:
+        if world == 1 and not variable and not args.no_variable and args.ic == "disc" and not args.self_gravity:
             # BASELINE configs[2] on the same GPU, same step count
             vctx = make_single_ctx(capi, ic, torch, True, args.n, args.nngb, local_rank, 0)
             vel, vdt = timed_run(vctx, torch, args.steps, args.warmup)
