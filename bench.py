@@ -232,6 +232,8 @@ def main():
         st = ctx.stats()
         kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
         f_ms, f_cnt = kt["forces"]
+        if sim is not None and not args.self_gravity:
+            f_cnt = max(f_cnt // 2, 1)        # N > 1: one force pass = two launches (interior + boundary wavefronts)
         f_avg_s = f_ms / max(f_cnt, 1) * 1e-3
         bytes_forces = (BYTES_VAR if variable else BYTES)["forces"]
         alg_bytes = bytes_forces * args.n

@@ -1,0 +1,19 @@
+"""Host-side cost of the Python orchestrator: DistSim with one rank (no messages) against sph_run on the same workload."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+import torch
+from summersph_amd import capi, ic
+from summersph_amd.dist import DistSim, HipBackend
+
+n = 1000000
+gas, sinks = ic.split_rows(ic.keplerian_disc(n, seed=202, nngb=85.0))
+ctx = capi.Context(device=0); ctx.upload(gas); ctx.set_sinks(sinks)
+dt, t = ctx.run(2, 1e-2, 0.0); ctx.synchronize()
+t0 = time.perf_counter(); dt, t = ctx.run(10, dt, t); ctx.synchronize(); t1 = time.perf_counter()
+print("sph_run       ms/step", (t1 - t0) / 10 * 1e3)
+ctx.close()
+sim = DistSim(HipBackend(0), gas, sinks, np.zeros(0))
+d = sim.run(2, 1e-2); sim.be.synchronize()
+t0 = time.perf_counter(); d = sim.run(10, d); sim.be.synchronize(); torch.cuda.synchronize(); t1 = time.perf_counter()
+print("DistSim (P=1) ms/step", (t1 - t0) / 10 * 1e3, "final dt", d, dt)
