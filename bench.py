@@ -157,6 +157,8 @@ def main():
                     "BASELINE configs[3]'s thin ring r ~ N(r0, 0.05 r0) (artificial viscosity at work)")
     ap.add_argument("--self-gravity", action="store_true", help="SPH_FLAG_SELF_GRAVITY in the headline run (NOT the "
                     "default workload): Barnes-Hut gas self-gravity; with --gpus > 1 every rank builds the replicated tree")
+    ap.add_argument("--full-simulate", action="store_true", help="the reference's whole loop body in the headline run (NOT the "
+                    "default workload): --self-gravity plus sink accretion and the boundary cull, on any number of GPUs")
     ap.add_argument("--dist-profile", action="store_true", help="N>1: synchronise at phase boundaries and report wall "
                     "time per phase of the distributed step (perturbs the headline value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -182,12 +184,15 @@ def main():
             dist.init_process_group(backend="gloo")
     red_dev = f"cuda:{local_rank}" if (world == 1 or args.backend == "nccl") else "cpu"
 
+    if args.full_simulate:
+        args.self_gravity = True
     variable = args.mode == "variable"
     if variable and world > 1:
         raise SystemExit("the variable-h path is single-GPU this round (its octree leaf boxes need the global particle "
                          "set); use --mode fixed for --gpus > 1")
     flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
-        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0)
+        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0) \
+        | (capi.FLAG_ACCRETE_CULL if args.full_simulate else 0)
 
     # ---- headline workload -----------------------------------------------------------------------
     sim = None
@@ -255,7 +260,8 @@ def main():
               + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
                  if variable else "fixed h=2.5 ([F] path, BASELINE configs[1] shape at the metric's N=1e6), ")
               + f"mean {st.nlist_mean:.1f} list entries per particle, 2 density + 2 force passes per step"
-              + (", Barnes-Hut gas self-gravity (theta 0.5)" if args.self_gravity else ""))
+              + (", Barnes-Hut gas self-gravity (theta 0.5)" if args.self_gravity else "")
+              + (", sink accretion + boundary cull" if args.full_simulate else ""))
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

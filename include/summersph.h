@@ -239,8 +239,18 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     box {min xyz, max xyz} (host).  The Barnes-Hut tree is then built over these sources -- with
  *                     every GPU's particles all-gathered into them it is the SAME tree on every GPU as the single
  *                     tree of the undecomposed run -- and walked for the context's owned particles.  n_src = 0: back
- *                     to the context's own particles.                                                        */
+ *                     to the context's own particles.
+ * sph_accrete_mark_dev / sph_accrete_apply_dev  sink accretion + boundary cull ([F]:471-556) when the octree is that of
+ *                     all GPUs' particles (after sph_forces with sph_set_gravity_sources_dev; src_offset = position
+ *                     of this GPU's owned particles, in the caller's order, inside the source set).  mark: decides for
+ *                     the owned particles and writes this GPU's sums per sink (m, m x, m y, m z, m vx, m vy, m vz:
+ *                     SPH_ACC_PARTIALS doubles) to d_partials; the caller all-gathers them.  apply: sink update from the
+ *                     sums of all ranks (rank order), then the context keeps only the surviving OWNED particles, in
+ *                     the caller's order (ghosts are dropped); d_keep (optional) receives keep[0..n_owned_before).  */
 #define SPH_PARTIALS 193
+#define SPH_ACC_PARTIALS 448
+int sph_accrete_mark_dev(sph_ctx *ctx, int64_t src_offset, double *d_partials);
+int sph_accrete_apply_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t *d_keep, int64_t *n_removed);
 int sph_set_gravity_sources_dev(sph_ctx *ctx, int64_t n_src, const double *d_xyzm, const double *lo_hi);
 int sph_set_boundary_boxes(sph_ctx *ctx, int32_t nbox, const double *boxes);
 int sph_forces_part(sph_ctx *ctx, int32_t part);

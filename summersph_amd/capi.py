@@ -36,7 +36,7 @@ SYMBOLS = [
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_pack_partials_dev",
-    "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev",
+    "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
@@ -135,6 +135,8 @@ def load():
     lib.sph_set_boundary_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.sph_forces_part.argtypes = [C.c_void_p, C.c_int32]
     lib.sph_set_gravity_sources_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sph_accrete_mark_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.sph_accrete_apply_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
     _lib = lib
@@ -345,6 +347,15 @@ class Context:
         box = np.ascontiguousarray(lo_hi, dtype=np.float64) if n_src else np.zeros(6)
         self._ck(self.lib.sph_set_gravity_sources_dev(self._h, int(n_src), C.c_void_p(int(dev_ptr)) if n_src else None,
                                                       box.ctypes.data))
+
+    def accrete_mark_dev(self, src_offset: int, partials_ptr: int):
+        self._ck(self.lib.sph_accrete_mark_dev(self._h, int(src_offset), C.c_void_p(int(partials_ptr))))
+
+    def accrete_apply_dev(self, all_ptr: int, nranks: int, stride: int, keep_ptr: int = 0) -> int:
+        r = C.c_int64(0)
+        self._ck(self.lib.sph_accrete_apply_dev(self._h, C.c_void_p(int(all_ptr)), nranks, stride,
+                                                C.c_void_p(int(keep_ptr)) if keep_ptr else None, C.byref(r)))
+        return int(r.value)
 
     def refresh_eos(self):
         self._ck(self.lib.sph_refresh_eos(self._h))

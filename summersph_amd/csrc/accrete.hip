@@ -99,6 +99,77 @@ __global__ __launch_bounds__(AB) void acc_mark(RootBox rb, const uint64_t *__res
     keep[orig[slot]] = (mask == 0ull && inside) ? 1 : 0;
 }
 
+// Multi-GPU: the octree is that of ALL GPUs' particles (the external gravity sources: keys / vals are their sorted
+// path keys and source indices).  Every GPU looks at all leaves but only marks its own particles: source indices
+// [src_off, src_off + n_owned) are this GPU's owned particles in the caller's order.  keep[] / accmask[] were zeroed
+// (ghosts are dropped with the accreted particles; they are exchanged again before the next evaluation).
+__global__ __launch_bounds__(AB) void acc_mark_ext(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                   int64_t n_glob, int64_t src_off, int64_t n_owned, const double4 *__restrict__ drec,
+                                                   const int32_t *__restrict__ inv, const double *__restrict__ sink,
+                                                   const double *__restrict__ srad, int ns, int do_accrete, double bound,
+                                                   int32_t *__restrict__ keep, unsigned long long *__restrict__ accmask) {
+    const int64_t s = (int64_t)blockIdx.x * AB + threadIdx.x;
+    if (s >= n_glob) return;
+    const int64_t id = (int64_t)vals[s] - src_off;
+    if (id < 0 || id >= n_owned) return;
+    const uint64_t key = keys[s];
+    int cp = 0;
+    if (s > 0) cp = max(cp, common_levels(key, keys[s - 1]));
+    if (s + 1 < n_glob) cp = max(cp, common_levels(key, keys[s + 1]));
+    const int level = n_glob == 1 ? 0 : min(cp + 1, LEVELS);
+    const int32_t slot = inv[id];
+    const double4 p = drec[slot];
+    unsigned long long mask = 0ull;
+    if (do_accrete) {
+        for (int k = 0; k < ns; k++) {
+            const double sx = sink[0 * MAX_SINKS + k], sy = sink[1 * MAX_SINKS + k], sz = sink[2 * MAX_SINKS + k];
+            const double rad = srad[k];
+            double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+            bool reached = true;
+            for (int l = 1; l <= level; l++) {
+                const double lim = rad + size / 2.0;                                         // [F]:529
+                if (!(fabs(cx - sx) < lim && fabs(cy - sy) < lim && fabs(cz - sz) < lim)) { reached = false; break; }
+                const int ch = (int)((key >> (3 * (LEVELS - l))) & 7);
+                const double q = 0.25 * size;
+                cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+                size = size * 0.5;
+            }
+            if (!reached) continue;
+            const double lim = 2 * rad + size / 2.0;                                         // [F]:536
+            if (!(fabs(cx - sx) < lim && fabs(cy - sy) < lim && fabs(cz - sz) < lim)) continue;
+            const double dr = sqrt(cx * cx - sx * sx) + sqrt(cy * cy - sy * sy) + sqrt(cz * cz - sz * sz);   // [F]:537
+            if (dr < rad) mask |= 1ull << k;
+        }
+    }
+    accmask[slot] = mask;
+    const bool inside = fabs(p.x) <= bound && fabs(p.y) <= bound && fabs(p.z) <= bound;       // [F]:478
+    keep[id] = (mask == 0ull && inside) ? 1 : 0;
+}
+
+// sink k: sums over ranks (rank order) of the per-rank sums, then [F]:497-508
+__global__ void acc_sink_update_ranks(int ns, const double *__restrict__ all, int nranks, int stride, double *__restrict__ sink) {
+    const int k = threadIdx.x;
+    if (k >= ns) return;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < nranks; r++)
+        for (int q = 0; q < 7; q++) v[q] += all[(size_t)r * stride + (size_t)k * 7 + q];
+    const double m0 = sink[6 * MAX_SINKS + k];
+    const double nm = m0 + v[0];
+    for (int a = 0; a < 3; a++) {
+        sink[a * MAX_SINKS + k] = (m0 * sink[a * MAX_SINKS + k] + v[1 + a]) / nm;
+        sink[(3 + a) * MAX_SINKS + k] = (m0 * sink[(3 + a) * MAX_SINKS + k] + v[4 + a]) / nm;
+    }
+    sink[6 * MAX_SINKS + k] = m0 + v[0];
+}
+
+// one block per sink: the fixed-order total of the per-block partial sums -> out[k*7 .. k*7+7)
+__global__ void acc_partials_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
+    if (threadIdx.x >= 7) return;
+    double r = 0.0;
+    for (int b = 0; b < nb; b++) r += part[(size_t)b * 7 + threadIdx.x];
+    out[threadIdx.x] = r;
+}
+
 __device__ __forceinline__ double wave_sumd(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -236,6 +307,87 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = false;
     *removed = n - n_new;
+    return SPH_OK;
+}
+
+// ---- multi-GPU: mark + per-rank sums, then (after the caller all-gathered the sums) sink update + compaction ----------
+int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
+    if (!c->gx_src || !c->tree_valid) { c->err = "sph_accrete_mark_dev: needs the tree of the all-gathered sources (sph_forces after sph_set_gravity_sources_dev)"; return SPH_ERR_STATE; }
+    if (c->variable) { c->err = "sph_accrete_mark_dev: fixed-h contexts only"; return SPH_ERR_STATE; }
+    const int64_t n = c->n, no = c->n_owned, ng = c->gx_n;
+    if (src_off < 0 || src_off + no > ng) { c->err = "sph_accrete_mark_dev: owned block outside the source set"; return SPH_ERR_ARG; }
+    RootBox rb;
+    double size = 0.0;
+    for (int a = 0; a < 3; a++) {
+        rb.c[a] = (c->gx_box[3 + a] + c->gx_box[a]) / 2.0;
+        size = std::max(size, c->gx_box[3 + a] - c->gx_box[a]);
+    }
+    rb.size = size;
+    std::vector<double> sm((size_t)MAX_SINKS);
+    AC_CHECK(hipMemcpyAsync(sm.data(), c->sink + (size_t)6 * MAX_SINKS, sizeof(double) * MAX_SINKS, hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    bool any_mass = false;
+    for (int k = 0; k < c->ns; k++) any_mass |= sm[k] > 0.0;
+    int32_t *keep = reinterpret_cast<int32_t *>(c->keys);
+    unsigned long long *accmask = reinterpret_cast<unsigned long long *>(c->scratch);
+    AC_CHECK(hipMemsetAsync(keep, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1), c->stream));
+    AC_CHECK(hipMemsetAsync(accmask, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(n, 1), c->stream));
+    AC_CHECK(hipMemsetAsync(d_partials, 0, sizeof(double) * 7 * MAX_SINKS, c->stream));
+    if (no > 0 && ng > 0)
+        acc_mark_ext<<<dim3((unsigned)((ng + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(
+            rb, c->g_keys_alt, c->g_vals_alt, ng, src_off, no, reinterpret_cast<const double4 *>(c->drec), c->inv, c->sink,
+            c->sink_radius, c->ns, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
+    AC_CHECK(hipGetLastError());
+    if (any_mass && n > 0) {
+        const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
+        for (int k = 0; k < c->ns; k++) {
+            acc_sums_partial<<<dim3(nb), dim3(AB), 0, c->stream>>>(n, k, accmask, reinterpret_cast<const double4 *>(c->drec),
+                                                                   c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->sink_part);
+            acc_partials_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->sink_part, nb, d_partials + (size_t)k * 7);
+        }
+        AC_CHECK(hipGetLastError());
+    }
+    c->acc_marked = true;
+    c->acc_any_mass = any_mass;
+    return SPH_OK;
+}
+
+int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, int32_t *d_keep_out, int64_t *removed) {
+    *removed = 0;
+    if (!c->acc_marked) { c->err = "sph_accrete_apply_dev: call sph_accrete_mark_dev first"; return SPH_ERR_STATE; }
+    c->acc_marked = false;
+    const int64_t n = c->n, no = c->n_owned;
+    if (c->acc_any_mass && c->ns > 0)
+        acc_sink_update_ranks<<<dim3(1), dim3(64), 0, c->stream>>>(c->ns, d_all, nranks, stride, c->sink);
+    AC_CHECK(hipGetLastError());
+    int32_t *keep = reinterpret_cast<int32_t *>(c->keys);
+    int32_t *pos = reinterpret_cast<int32_t *>(c->keys_alt);
+    if (d_keep_out && no > 0) AC_CHECK(hipMemcpyAsync(d_keep_out, keep, sizeof(int32_t) * (size_t)no, hipMemcpyDeviceToDevice, c->stream));
+    int64_t n_new = 0;
+    if (n > 0) {
+        size_t sb = 0;
+        AC_CHECK(rocprim::exclusive_scan(nullptr, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
+        if (sb > c->sort_tmp_bytes) { c->err = "accrete: scan scratch too small"; return SPH_ERR_NOMEM; }
+        AC_CHECK(rocprim::exclusive_scan(c->sort_tmp, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
+        int32_t last[2];
+        AC_CHECK(hipMemcpyAsync(&last[0], pos + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        AC_CHECK(hipMemcpyAsync(&last[1], keep + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        AC_CHECK(hipStreamSynchronize(c->stream));
+        n_new = (int64_t)last[0] + last[1];
+        CompactArgs ca{};
+        for (int k = 0; k < 9; k++) { ca.src[k] = c->f[k]; ca.dst[k] = c->f_alt[k]; }
+        ca.nf = 9;
+        acc_compact<<<dim3((unsigned)((n + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(ca, keep, pos, c->inv, n);
+        AC_CHECK(hipGetLastError());
+        for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
+    }
+    *removed = no - n_new;                             // owned particles that left; the ghosts are dropped as well
+    c->n = n_new; c->n_slots = n_new; c->dead_below = 0;
+    c->n_owned = n_new;
+    AC_CHECK(launch_iota(c, c->orig, n_new));
+    AC_CHECK(launch_iota(c, c->inv, n_new));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
     return SPH_OK;
 }
 

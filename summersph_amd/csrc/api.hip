@@ -808,6 +808,21 @@ int sph_set_gravity_sources_dev(sph_ctx *c, int64_t n_src, const double *d_xyzm,
     return SPH_OK;
 }
 
+int sph_accrete_mark_dev(sph_ctx *c, int64_t src_offset, double *d_partials) {
+    if (!c || !d_partials) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return accrete_mark_ext(c, src_offset, d_partials);
+}
+
+int sph_accrete_apply_dev(sph_ctx *c, const double *d_all, int32_t nranks, int32_t stride, int32_t *d_keep, int64_t *n_removed) {
+    if (!c || !d_all || nranks < 1 || stride < 7 * MAX_SINKS) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    int64_t r = 0;
+    const int st = accrete_apply_ext(c, d_all, nranks, stride, d_keep, &r);
+    if (n_removed) *n_removed = r;
+    return st;
+}
+
 int sph_set_dt(sph_ctx *c, double dt, double t) {
     if (!c) return SPH_ERR_ARG;
     DeviceGuard g(c->device);

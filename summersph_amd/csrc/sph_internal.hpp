@@ -116,6 +116,7 @@ struct sph_ctx {
     double *grav_tab = nullptr;                      // softening table, [F]:81-101
     uint64_t *g_keys = nullptr, *g_keys_alt = nullptr; uint32_t *g_vals = nullptr, *g_vals_alt = nullptr;
     void *g_sort_tmp = nullptr; size_t g_sort_tmp_bytes = 0;
+    bool acc_marked = false, acc_any_mass = false;  // multi-GPU accretion: between sph_accrete_mark_dev and _apply_dev
     int64_t g_cap = 0;                               // leaves the tree arrays hold
     // external gravity sources (multi-GPU: the particles of every GPU), caller-owned {x,y,z,m} records + their bounding box
     const double *gx_src = nullptr; int64_t gx_n = 0; double gx_box[6] = {0, 0, 0, 0, 0, 0};
@@ -220,6 +221,8 @@ void gravity_free(sph_ctx *c);
 hipError_t launch_gravity(sph_ctx *c);
 // accretion + boundary cull (accrete.hip)
 int accrete_and_cull(sph_ctx *c, int64_t *removed);
+int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials);       // multi-GPU: marks + per-rank sink sums
+int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, int32_t *d_keep_out, int64_t *removed);
 // variable-h path (varh.hip)
 hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)

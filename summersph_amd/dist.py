@@ -45,6 +45,7 @@ import torch.distributed as dist
 
 STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
 PARTIALS = 193          # SPH_PARTIALS: ax[64] ay[64] az[64] of the sinks + the dt candidate
+ACC_PARTIALS = 448      # SPH_ACC_PARTIALS: per sink m, m x, m y, m z, m vx, m vy, m vz of the accreted particles
 
 
 class HipBackend:
@@ -140,6 +141,24 @@ class HipBackend:
         self._grav_src = src.contiguous()
         self.ctx.set_gravity_sources_dev(int(self._grav_src.shape[0]), self._grav_src.data_ptr(), lo_hi)
 
+    @property
+    def accrete(self) -> bool:
+        return bool(self.ctx.params.flags & self.capi.FLAG_ACCRETE_CULL)
+
+    def accrete_mark(self, src_offset: int) -> torch.Tensor:
+        out = torch.empty(ACC_PARTIALS, dtype=torch.float64, device=self.device)
+        self.ctx.accrete_mark_dev(src_offset, out.data_ptr())
+        return out
+
+    def accrete_apply(self, allp: torch.Tensor):
+        """-> (owned particles removed, keep flags [n_owned before] as a bool tensor)"""
+        allp = allp.contiguous()
+        keep = torch.empty(max(self.n_owned, 1), dtype=torch.int32, device=self.device)
+        removed = self.ctx.accrete_apply_dev(allp.data_ptr(), int(allp.shape[0]), int(allp.shape[1]), keep.data_ptr())
+        keep = keep[:self.n_owned].bool()
+        self.n_owned -= removed
+        return removed, keep
+
     def forces_interior(self):
         self.ctx.forces_part(1)
 
@@ -217,6 +236,13 @@ class DistSim:
         self.t = 0.0
         self.stats = {"ghosts": 0, "migrated": 0, "exchanges": 0, "migrations": 0}
         self.gravity = bool(getattr(backend, "gravity", False))     # Barnes-Hut self-gravity: replicated tree (below)
+        # sink accretion + boundary cull at the end of a step ([F]:918-920); decided on the octree of all particles,
+        # i.e. it needs the all-gathered sources of the self-gravity path
+        self.accrete = bool(getattr(backend, "accrete", False))
+        if self.accrete and (self.P == 1 or not self.gravity):
+            raise ValueError("accretion through DistSim needs several ranks and SPH_FLAG_SELF_GRAVITY (the shared octree); "
+                             "a single GPU runs it inside sph_step / sph_run")
+        self.stats_removed = 0
         self.counts_all = None    # owned particles of every rank (changes with migrations only)
         self.boxes = None         # every rank's owned bounding box at the last ghost exchange (host)
         self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
@@ -380,7 +406,7 @@ class DistSim:
         if self.counts_all is None:
             self.counts_all = [int(v) for v in self._all_gather(torch.tensor([self.n_owned], dtype=torch.int64)).cpu()[:, 0]]
         mine = be.gather(["x", "y", "z", "m"], None, self.n_owned)            # [4, n_owned]
-        maxn = max(self.counts_all)
+        maxn = max(max(self.counts_all), 1)
         buf = torch.zeros((4, maxn), dtype=torch.float64, device=self.dev)
         buf[:, :self.n_owned] = mine
         allb = self._all_gather(buf.view(-1)).to(self.dev).view(self.P, 4, maxn)
@@ -486,6 +512,24 @@ class DistSim:
             be.dt_candidate_local()          # get_next_timestep's local part, [F]:845-851; reduced with the next exchange
         self.vel_dirty = True
         self.dt_pending = True
+        if self.accrete and self.P > 1:
+            with self._phase("accrete"):
+                self._accrete_and_cull()
+
+    def _accrete_and_cull(self):
+        """every rank decides for its own particles on the shared octree; the sums over the accreted particles are
+        all-gathered and added in rank order, so every rank updates the (replicated) sinks identically"""
+        be = self.be
+        off = sum(self.counts_all[:self.rank])
+        allp = self._all_gather(be.accrete_mark(off)).to(self.dev)
+        removed, keep = be.accrete_apply(allp)
+        if removed:
+            self.gid = self.gid[keep]
+        self.n_owned = int(self.gid.numel())
+        self.stats_removed += removed
+        self.counts_all = None
+        self.pos_dirty = True          # the ghosts were dropped with the accreted particles: exchange before the next pass
+        self.vel_dirty = False
 
     def _finish_dt(self):
         """reduce a pending dt candidate now (end of a run): t += dt and [F]:855-858 on every rank"""

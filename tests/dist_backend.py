@@ -19,8 +19,10 @@ def _p(a):
 class OracleBackend:
     STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
 
-    def __init__(self, h=2.5, nq=5000, gravity=False):
+    def __init__(self, h=2.5, nq=5000, gravity=False, accrete=False, bounding_size=1500.0):
         self.gravity = gravity
+        self.accrete = accrete
+        self.bound = bounding_size
         self.gtree = None
         self.device = torch.device("cpu")
         self.h, self.nq = h, nq
@@ -79,6 +81,7 @@ class OracleBackend:
                 self._ghost_rho = self.f["rho"][self.n_owned:].copy()
 
     def set_sinks(self, s):
+        self.srad = np.array(s.get("radius", np.full(np.asarray(s["x"]).size, 3.5)), dtype=np.float64, copy=True)
         self.s = {k: np.array(s[k], dtype=np.float64, copy=True) for k in "x y z vx vy vz m".split()}
         ns = self.s["x"].size
         for k in ("ax", "ay", "az"):
@@ -172,6 +175,59 @@ class OracleBackend:
         from oracle import orc_grav
         s = src.cpu().numpy()
         self.gtree = orc_grav.Tree(*[np.ascontiguousarray(s[:, k]) for k in range(4)])   # root box = bbox of the sources
+
+    # accretion + cull on the octree of all ranks' particles (the gravity sources), [F]:471-556
+    def accrete_mark(self, src_offset):
+        from oracle import orc_grav
+        lib = orc_grav.lib()
+        t, s, o = self.gtree, self.s, self.n_owned
+        ng = t._keep[0].size
+        zero = np.zeros(ng)
+        ns = s["x"].size
+        self._keep = np.ones(o, dtype=bool)
+        part = np.zeros(448)
+        f = self.f
+        if np.any(s["m"] > 0.0):
+            for k in range(ns):                       # one sink at a time: which particles does IT accrete
+                keep = np.ones(ng, dtype=np.uint8)
+                cp = {q: np.array([s[q][k]]) for q in ("x", "y", "z", "vx", "vy", "vz", "m")}
+                rad = np.array([self.srad[k]])
+                lib.orcg_accrete(t.h, C.c_int(ng), _p(zero), _p(zero), _p(zero), C.c_int(1), _p(cp["x"]), _p(cp["y"]), _p(cp["z"]),
+                                 _p(cp["vx"]), _p(cp["vy"]), _p(cp["vz"]), _p(cp["m"]), _p(rad), C.c_int(0),
+                                 keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
+                acc = ~keep[src_offset:src_offset + o].astype(bool)
+                m = f["m"][:o][acc]
+                part[7 * k:7 * k + 7] = [m.sum(), (m * f["x"][:o][acc]).sum(), (m * f["y"][:o][acc]).sum(), (m * f["z"][:o][acc]).sum(),
+                                         (m * f["vx"][:o][acc]).sum(), (m * f["vy"][:o][acc]).sum(), (m * f["vz"][:o][acc]).sum()]
+                self._keep &= ~acc
+        inside = (np.abs(f["x"][:o]) <= self.bound) & (np.abs(f["y"][:o]) <= self.bound) & (np.abs(f["z"][:o]) <= self.bound)
+        self._keep &= inside
+        self._any_mass = bool(np.any(s["m"] > 0.0))
+        return torch.from_numpy(part)
+
+    def accrete_apply(self, allp):
+        a = allp.cpu().numpy()
+        s = self.s
+        if self._any_mass:
+            for k in range(s["x"].size):
+                v = np.zeros(7)
+                for r in range(a.shape[0]):
+                    v = v + a[r, 7 * k:7 * k + 7]
+                m0 = s["m"][k]
+                nm = m0 + v[0]
+                for i, q in enumerate(("x", "y", "z")):
+                    s[q][k] = (m0 * s[q][k] + v[1 + i]) / nm
+                for i, q in enumerate(("vx", "vy", "vz")):
+                    s[q][k] = (m0 * s[q][k] + v[4 + i]) / nm
+                s["m"][k] = m0 + v[0]
+        keep = self._keep
+        o = self.n_owned
+        removed = int(o - keep.sum())
+        for k in list(self.f):
+            self.f[k] = np.ascontiguousarray(self.f[k][:o][keep])
+        self.n = self.n_owned = int(keep.sum())
+        self._ghost_rho = None
+        return removed, torch.from_numpy(keep.copy())
 
     # split evaluation: the oracle backend does everything in the second part (after the ghost fields arrived)
     def set_boundary_boxes(self, boxes):

@@ -75,3 +75,45 @@ def test_hip_self_gravity_replicated_tree(tmp_path):
     for f in FIELDS:
         merged = np.concatenate([p[f] for p in parts])[order]
         assert rel_err(merged, g["full_s5_" + f]) <= 1e-11, f
+
+
+def _worker_acc(rank, world, port, nsteps, outdir, ic_rows):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from summersph_amd import capi, ic
+    from summersph_amd.dist import DistSim, HipBackend, slab_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    gas, sinks = ic.split_rows(ic_rows)
+    bounds = slab_bounds(gas["x"], world)
+    sel = np.searchsorted(bounds, gas["x"], side="right") == rank
+    mine = {k: v[sel] for k, v in gas.items()}
+    mine["gid"] = np.nonzero(sel)[0]
+    be = HipBackend(0, flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    sim = DistSim(be, mine, sinks, bounds, comm_device="cpu", migrate_every=2)
+    dts, ns = [1e-2], []
+    for _ in range(nsteps):
+        dts.append(sim.step(dts[-1]))
+        ns.append(sim.n_owned)
+    st = sim.gather_state()
+    s = sim.be.get_sinks()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), dts=np.array(dts), ns=np.array(ns), sm=s["m"], sx=s["x"], svx=s["vx"], **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hip_accretion_and_cull_across_ranks(tmp_path):
+    """the reference's whole loop body on 2 ranks (shared-tree gravity, accretion, cull): 2000 -> 1996 particles"""
+    g = load_golden("acc2000_traj")
+    mp.spawn(_worker_acc, args=(2, _free_port(), 3, str(tmp_path), g["ic"]), nprocs=2, join=True)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    ns = parts[0]["ns"] + parts[1]["ns"]
+    assert list(ns) == [int(v) for v in g["full_n_seq"][1:]]
+    gid = np.concatenate([p["gid"] for p in parts])
+    order = np.argsort(gid)
+    assert np.unique(gid).size == gid.size == 1996
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert abs(p["sm"][0] - g["full_s3_sm"][0]) <= 1e-15 and abs(p["sx"][0] - g["full_s3_sx"][0]) <= 1e-12
+        assert np.array_equal(p["sm"], parts[0]["sm"])
+    for f in FIELDS:
+        assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-11, f
