@@ -256,3 +256,32 @@ def test_upload_from_device_memory(capi):
     b.field_dev("rho", out.data_ptr(), out.numel())
     assert np.array_equal(out.cpu().numpy(), a.field("rho"))
     a.close(); b.close()
+
+
+def test_north_star_acceptance_numbers(capi):
+    """BASELINE.json's own criteria, stated as such: Sod shock tube L2 density error vs the reference < 1e-6 (after 5
+    steps of the loop), and the Keplerian disc's energy after 40 steps equal to the reference's (same energy drift)."""
+    g = load_golden("sod1000_traj")
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    dt, t = ctx.run(5, 1e-2, 0.0)
+    ctx.density()
+    rho = ctx.field("rho")
+    l2 = np.sqrt(np.mean((rho - g["sph_s5_rho"]) ** 2)) / np.sqrt(np.mean(g["sph_s5_rho"] ** 2))
+    assert l2 < 1e-6 and l2 < 1e-12            # the criterion, and what is actually achieved
+    ctx.close()
+
+    g = load_golden("disc3000_long")
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    m = gas["m"]
+
+    def energy(vx, vy, vz, u):                 # kinetic + thermal (the potential depends on positions, compared below)
+        return float(np.sum(m * (0.5 * (vx ** 2 + vy ** 2 + vz ** 2) + u)))
+
+    e0 = energy(gas["vx"], gas["vy"], gas["vz"], gas["u"])
+    dt, t = ctx.run(40, 1e-2, 0.0)
+    e_mine = energy(ctx.field("vx"), ctx.field("vy"), ctx.field("vz"), ctx.field("u"))
+    e_ref = energy(g["sph_s40_vx"], g["sph_s40_vy"], g["sph_s40_vz"], g["sph_s40_u"])
+    assert abs(e_mine - e_ref) <= 1e-10 * abs(e_ref)
+    assert abs((e_mine - e0) - (e_ref - e0)) <= 1e-7 * abs(e_ref - e0)      # the drift itself, to 7 digits
+    assert rel_err(ctx.field("x"), g["sph_s40_x"]) <= 1e-9
+    ctx.close()
