@@ -269,6 +269,8 @@ int sph_pack_partials_dev(sph_ctx *ctx, double *d_out);
 int sph_apply_partials_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt);
 /* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */
 int sph_refresh_eos(sph_ctx *ctx);
+/* the same for the ghost slots only (the owned particles' records are written by sph_density itself) */
+int sph_refresh_eos_ghosts(sph_ctx *ctx);
 /* the local part of get_next_timestep ([F]:845-851): min over OWNED particles * dt_scale;
  * the caller min-reduces over ranks and applies [F]:855-858                                */
 int sph_dt_candidate(sph_ctx *ctx, double *candidate);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
-    "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_dt_candidate", "sph_set_sink_accel",
+    "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_refresh_eos_ghosts", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_pack_partials_dev",
     "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev",
@@ -118,6 +118,7 @@ def load():
     lib.sph_gather_fields_dev.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_void_p]
     lib.sph_scatter_fields_dev.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_void_p]
     lib.sph_refresh_eos.argtypes = [C.c_void_p]
+    lib.sph_refresh_eos_ghosts.argtypes = [C.c_void_p]
     lib.sph_dt_candidate.argtypes = [C.c_void_p, _D]
     lib.sph_set_sink_accel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sph_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -357,8 +358,8 @@ class Context:
                                                 C.c_void_p(int(keep_ptr)) if keep_ptr else None, C.byref(r)))
         return int(r.value)
 
-    def refresh_eos(self):
-        self._ck(self.lib.sph_refresh_eos(self._h))
+    def refresh_eos(self, ghosts_only: bool = False):
+        self._ck((self.lib.sph_refresh_eos_ghosts if ghosts_only else self.lib.sph_refresh_eos)(self._h))
 
     def dt_candidate(self) -> float:
         d = C.c_double(0)

@@ -695,16 +695,20 @@ int sph_scatter_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_
     return SPH_OK;
 }
 
-int sph_refresh_eos(sph_ctx *c) {
+static int refresh_eos_impl(sph_ctx *c, bool ghosts_only) {
     if (!c) return SPH_ERR_ARG;
     if (!c->grid_valid || !c->rho_valid) { c->err = "sph_refresh_eos: density is stale"; return SPH_ERR_STATE; }
     DeviceGuard g(c->device);
     const PairConst pc = make_pair_const(c);
     Timed t(c, SPH_K_DENSITY);
-    API_HIP(launch_eos_only(c, pc));
+    if (c->variable) API_HIP(launch_eos_only_v(c, pc));
+    else API_HIP(launch_eos_only(c, pc, ghosts_only));
     c->eos_valid = true;
     return SPH_OK;
 }
+
+int sph_refresh_eos(sph_ctx *c) { return refresh_eos_impl(c, false); }
+int sph_refresh_eos_ghosts(sph_ctx *c) { return refresh_eos_impl(c, true); }
 
 int sph_dt_candidate(sph_ctx *c, double *cand) {
     if (!c || !cand) return SPH_ERR_ARG;

@@ -26,8 +26,10 @@ struct InBox {
     double lo[3], hi[3];
     __device__ bool operator()(const int64_t &id) const {
         const int32_t s = inv[id];
-        const double px = x[s], py = y[s], pz = z[s];
-        return px >= lo[0] && px <= hi[0] && py >= lo[1] && py <= hi[1] && pz >= lo[2] && pz <= hi[2];
+        const double px = x[s];
+        if (!(px >= lo[0] && px <= hi[0])) return false;        // slabs: almost every particle stops here
+        const double py = y[s], pz = z[s];
+        return py >= lo[1] && py <= hi[1] && pz >= lo[2] && pz <= hi[2];
     }
 };
 

@@ -182,9 +182,11 @@ __global__ __launch_bounds__(256) void eos_only_kernel(PairConst pc, int64_t n, 
                                                        const double *__restrict__ vx, const double *__restrict__ vy,
                                                        const double *__restrict__ vz, const double *__restrict__ rho,
                                                        double *__restrict__ P, double *__restrict__ cs,
-                                                       double *__restrict__ frec) {
+                                                       double *__restrict__ frec, const int32_t *__restrict__ orig,
+                                                       int32_t skip_below) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (orig && orig[i] < skip_below) return;          // ghosts only: the owned records are current (density epilogue)
     const double r = rho[i];
     const double Pi = pc.gamma_m1 * u[i] * r;
     const double ci = sqrt(pc.gamma * Pi / r);
@@ -427,11 +429,12 @@ hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     return hipGetLastError();
 }
 
-hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc) {
+hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc, bool ghosts_only) {
     if (c->n == 0) return hipSuccess;
     eos_only_kernel<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(
         pc, c->n, reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
-        c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec);
+        c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec,
+        ghosts_only ? c->orig : nullptr, (int32_t)c->n_owned);
     return hipGetLastError();
 }
 

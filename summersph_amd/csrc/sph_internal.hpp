@@ -190,7 +190,7 @@ int grid_rebuild(sph_ctx *c);
 // builds the neighbour list; synchronises once (overflow check), grows the list if needed
 int nlist_build(sph_ctx *c);
 hipError_t launch_density(sph_ctx *c, const PairConst &pc);
-hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc);
+hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc, bool ghosts_only = false);
 hipError_t launch_forces(sph_ctx *c, const PairConst &pc, int part = 0);
 hipError_t launch_classify_waves(sph_ctx *c);
 hipError_t launch_sink_accel(sph_ctx *c, const PairConst &pc);

@@ -124,7 +124,7 @@ class HipBackend:
         self.ctx.density()
 
     def refresh_eos(self):
-        self.ctx.refresh_eos()
+        self.ctx.refresh_eos(ghosts_only=True)      # owned records: written by the density pass itself
 
     def forces(self):
         self.ctx.forces()
