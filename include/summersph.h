@@ -246,8 +246,15 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     the owned particles and writes this GPU's sums per sink (m, m x, m y, m z, m vx, m vy, m vz:
  *                     SPH_ACC_PARTIALS doubles) to d_partials; the caller all-gathers them.  apply: sink update from the
  *                     sums of all ranks (rank order), then the context keeps only the surviving OWNED particles, in
- *                     the caller's order (ghosts are dropped); d_keep (optional) receives keep[0..n_owned_before).  */
+ *                     the caller's order (ghosts are dropped); d_keep (optional) receives keep[0..n_owned_before).
+ * sph_set_numbers_dev  variable h: the reference's particle numbers (the rank in the input file) of original ids
+ *                     [first, first + count).  The force pair {a, b} is evaluated iff the walk of the HIGHER-numbered
+ *                     partner reaches the other's leaf ([V]:383), so on several GPUs the numbers must be the global
+ *                     ones, for owned particles and ghosts alike.  Without this call: the context's own numbering.
+ *                     With SPH_FLAG_VARIABLE_H sph_replace_ghosts_dev takes 10 rows (.. alpha, h) and
+ *                     sph_set_gravity_sources_dev also supplies the octree the leaf boxes are taken from.            */
 #define SPH_PARTIALS 193
+int sph_set_numbers_dev(sph_ctx *ctx, int64_t first, int64_t count, const int64_t *d_numbers);
 #define SPH_ACC_PARTIALS 448
 int sph_accrete_mark_dev(sph_ctx *ctx, int64_t src_offset, double *d_partials);
 int sph_accrete_apply_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t *d_keep, int64_t *n_removed);

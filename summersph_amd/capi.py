@@ -36,7 +36,7 @@ SYMBOLS = [
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_refresh_eos_ghosts", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_pack_partials_dev",
-    "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev",
+    "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev", "sph_set_numbers_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
@@ -137,6 +137,7 @@ def load():
     lib.sph_forces_part.argtypes = [C.c_void_p, C.c_int32]
     lib.sph_set_gravity_sources_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sph_accrete_mark_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.sph_set_numbers_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.sph_accrete_apply_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
@@ -348,6 +349,10 @@ class Context:
         box = np.ascontiguousarray(lo_hi, dtype=np.float64) if n_src else np.zeros(6)
         self._ck(self.lib.sph_set_gravity_sources_dev(self._h, int(n_src), C.c_void_p(int(dev_ptr)) if n_src else None,
                                                       box.ctypes.data))
+
+    def set_numbers_dev(self, first: int, count: int, dev_ptr: int):
+        """global particle numbers (int64 on the device) of original ids [first, first + count)"""
+        self._ck(self.lib.sph_set_numbers_dev(self._h, int(first), int(count), C.c_void_p(int(dev_ptr)) if count else None))
 
     def accrete_mark_dev(self, src_offset: int, partials_ptr: int):
         self._ck(self.lib.sph_accrete_mark_dev(self._h, int(src_offset), C.c_void_p(int(partials_ptr))))

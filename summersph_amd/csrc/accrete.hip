@@ -106,7 +106,7 @@ __global__ __launch_bounds__(AB) void acc_mark(RootBox rb, const uint64_t *__res
 __global__ __launch_bounds__(AB) void acc_mark_ext(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                    int64_t n_glob, int64_t src_off, int64_t n_owned, const double4 *__restrict__ drec,
                                                    const int32_t *__restrict__ inv, const double *__restrict__ sink,
-                                                   const double *__restrict__ srad, int ns, int do_accrete, double bound,
+                                                   const double *__restrict__ srad, int ns, int variant, int do_accrete, double bound,
                                                    int32_t *__restrict__ keep, unsigned long long *__restrict__ accmask) {
     const int64_t s = (int64_t)blockIdx.x * AB + threadIdx.x;
     if (s >= n_glob) return;
@@ -135,9 +135,11 @@ __global__ __launch_bounds__(AB) void acc_mark_ext(RootBox rb, const uint64_t *_
                 size = size * 0.5;
             }
             if (!reached) continue;
-            const double lim = 2 * rad + size / 2.0;                                         // [F]:536
+            const double lim = (variant ? rad : 2 * rad) + size / 2.0;                       // [F]:536 / [V]:668
             if (!(fabs(cx - sx) < lim && fabs(cy - sy) < lim && fabs(cz - sz) < lim)) continue;
-            const double dr = sqrt(cx * cx - sx * sx) + sqrt(cy * cy - sy * sy) + sqrt(cz * cz - sz * sz);   // [F]:537
+            double dr;
+            if (variant) dr = sqrt((p.x - sx) * (p.x - sx)) + sqrt((p.y - sy) * (p.y - sy)) + sqrt((p.z - sz) * (p.z - sz));   // [V]:669
+            else dr = sqrt(cx * cx - sx * sx) + sqrt(cy * cy - sy * sy) + sqrt(cz * cz - sz * sz);                             // [F]:537
             if (dr < rad) mask |= 1ull << k;
         }
     }
@@ -312,8 +314,8 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
 
 // ---- multi-GPU: mark + per-rank sums, then (after the caller all-gathered the sums) sink update + compaction ----------
 int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
-    if (!c->gx_src || !c->tree_valid) { c->err = "sph_accrete_mark_dev: needs the tree of the all-gathered sources (sph_forces after sph_set_gravity_sources_dev)"; return SPH_ERR_STATE; }
-    if (c->variable) { c->err = "sph_accrete_mark_dev: fixed-h contexts only"; return SPH_ERR_STATE; }
+    if (!c->gx_src) { c->err = "sph_accrete_mark_dev: needs the all-gathered sources (sph_set_gravity_sources_dev)"; return SPH_ERR_STATE; }
+    { const int st = global_keys_sorted(c); if (st != SPH_OK) return st; }
     const int64_t n = c->n, no = c->n_owned, ng = c->gx_n;
     if (src_off < 0 || src_off + no > ng) { c->err = "sph_accrete_mark_dev: owned block outside the source set"; return SPH_ERR_ARG; }
     RootBox rb;
@@ -336,7 +338,7 @@ int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
     if (no > 0 && ng > 0)
         acc_mark_ext<<<dim3((unsigned)((ng + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(
             rb, c->g_keys_alt, c->g_vals_alt, ng, src_off, no, reinterpret_cast<const double4 *>(c->drec), c->inv, c->sink,
-            c->sink_radius, c->ns, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
+            c->sink_radius, c->ns, c->variable ? 1 : 0, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
     AC_CHECK(hipGetLastError());
     if (any_mass && n > 0) {
         const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
@@ -377,10 +379,13 @@ int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, i
         CompactArgs ca{};
         for (int k = 0; k < 9; k++) { ca.src[k] = c->f[k]; ca.dst[k] = c->f_alt[k]; }
         ca.nf = 9;
+        if (c->variable) { ca.src[9] = c->f[SPH_F_H]; ca.dst[9] = c->f_alt[9]; ca.nf = 10; }
         acc_compact<<<dim3((unsigned)((n + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(ca, keep, pos, c->inv, n);
         AC_CHECK(hipGetLastError());
         for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
+        if (c->variable) std::swap(c->f[SPH_F_H], c->f_alt[9]);
     }
+    c->numbers_set = false;                            // the caller's numbering has changed
     *removed = no - n_new;                             // owned particles that left; the ghosts are dropped as well
     c->n = n_new; c->n_slots = n_new; c->dead_below = 0;
     c->n_owned = n_new;

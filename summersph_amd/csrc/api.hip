@@ -38,7 +38,7 @@ struct DeviceGuard {
 void free_particle_arrays(sph_ctx *c) {
     for (auto &p : c->f) ctx_free(c, p);
     for (auto &p : c->f_alt) ctx_free(c, p);
-    ctx_free(c, c->orig); ctx_free(c, c->orig_alt); ctx_free(c, c->inv); ctx_free(c, c->scratch);
+    ctx_free(c, c->orig); ctx_free(c, c->orig_alt); ctx_free(c, c->inv); ctx_free(c, c->scratch); ctx_free(c, c->number);
     ctx_free(c, c->drec); ctx_free(c, c->frec);
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
@@ -60,6 +60,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     API_TRY(ctx_alloc(c, &c->orig, (size_t)cap, "ids"));
     API_TRY(ctx_alloc(c, &c->orig_alt, (size_t)cap, "ids (alt)"));
     API_TRY(ctx_alloc(c, &c->inv, (size_t)cap, "ids (inverse)"));
+    API_TRY(ctx_alloc(c, &c->number, (size_t)cap, "particle numbers"));
     API_TRY(ctx_alloc(c, &c->scratch, (size_t)cap, "scratch"));
     API_TRY(ctx_alloc(c, &c->drec, (size_t)cap * 4, "density records"));
     API_TRY(ctx_alloc(c, &c->frec, (size_t)cap * FREC, "force records"));
@@ -464,6 +465,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     DeviceGuard g(c->device);
     API_TRY(ensure_capacity(c, n));
     c->n = n; c->n_slots = n; c->dead_below = 0;
+    c->numbers_set = false;
     c->n_owned = n;
     for (int k = 0; k < 9; k++) {
         if (n == 0) break;
@@ -689,8 +691,8 @@ int sph_scatter_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_
     DeviceGuard g(c->device);
     API_HIP(launch_scatter_fields(c, nf, fields, first, count, d_vals));
     for (int f = 0; f < nf; f++) {
-        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; }
-        if (fields[f] <= SPH_F_ALPHA || fields[f] == SPH_F_RHO) c->eos_valid = false;
+        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M || fields[f] == SPH_F_H) { c->grid_valid = false; c->rho_valid = false; }
+        if (fields[f] <= SPH_F_ALPHA || fields[f] == SPH_F_RHO || fields[f] == SPH_F_H || fields[f] == SPH_F_OMEGA) c->eos_valid = false;
     }
     return SPH_OK;
 }
@@ -775,7 +777,6 @@ int sph_selected_ids_dev(sph_ctx *c, int32_t box, int64_t count, int64_t *d_ids)
 
 int sph_replace_ghosts_dev(sph_ctx *c, int64_t count, const double *d_state) {
     if (!c || count < 0 || (count > 0 && !d_state)) return SPH_ERR_ARG;
-    if (c->variable) { c->err = "sph_replace_ghosts_dev: fixed-h contexts only"; return SPH_ERR_STATE; }
     if (c->dead_below > 0) { c->err = "sph_replace_ghosts_dev: a ghost swap is already pending (call sph_density)"; return SPH_ERR_STATE; }
     DeviceGuard g(c->device);
     API_TRY(domain_replace_ghosts(c, count, d_state));
@@ -803,12 +804,14 @@ int sph_forces_part(sph_ctx *c, int32_t part) {
 
 int sph_set_gravity_sources_dev(sph_ctx *c, int64_t n_src, const double *d_xyzm, const double *lo_hi) {
     if (!c || n_src < 0 || (n_src > 0 && (!d_xyzm || !lo_hi))) return SPH_ERR_ARG;
-    if (!c->gravity) { c->err = "sph_set_gravity_sources_dev: context without SPH_FLAG_SELF_GRAVITY"; return SPH_ERR_STATE; }
+    if (!c->gravity && !c->variable) { c->err = "sph_set_gravity_sources_dev: needs SPH_FLAG_SELF_GRAVITY or SPH_FLAG_VARIABLE_H"; return SPH_ERR_STATE; }
     c->gx_src = n_src > 0 ? d_xyzm : nullptr;
     c->gx_n = n_src;
     for (int a = 0; a < 6; a++) c->gx_box[a] = n_src > 0 ? lo_hi[a] : 0.0;
+    c->gx_keys_valid = false;
     c->tree_valid = false;
     c->rates_valid = false;
+    if (c->variable) { c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; }      // the leaf boxes change
     return SPH_OK;
 }
 
@@ -825,6 +828,15 @@ int sph_accrete_apply_dev(sph_ctx *c, const double *d_all, int32_t nranks, int32
     const int st = accrete_apply_ext(c, d_all, nranks, stride, d_keep, &r);
     if (n_removed) *n_removed = r;
     return st;
+}
+
+int sph_set_numbers_dev(sph_ctx *c, int64_t first, int64_t count, const int64_t *d_numbers) {
+    if (!c || first < 0 || count < 0 || first + count > c->cap || (count > 0 && !d_numbers)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(launch_set_numbers(c, first, count, d_numbers));
+    c->numbers_set = true;
+    if (c->variable) { c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; }
+    return SPH_OK;
 }
 
 int sph_set_dt(sph_ctx *c, double dt, double t) {

@@ -33,15 +33,23 @@ struct InBox {
     }
 };
 
-// appends `count` ghosts behind the occupied slots: state fields from vals[f*count + k], original id n_owned + k
-__global__ __launch_bounds__(256) void append_ghosts(FieldPtrs9 fp, int32_t *__restrict__ orig,
+// appends `count` ghosts behind the occupied slots: state fields from vals[f*count + k] (row 9 = h when hfield is
+// given), original id n_owned + k
+__global__ __launch_bounds__(256) void append_ghosts(FieldPtrs9 fp, double *__restrict__ hfield, int32_t *__restrict__ orig,
                                                      int64_t first_slot, int64_t n_owned, int64_t count,
                                                      const double *__restrict__ vals) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
 #pragma unroll
     for (int f = 0; f < 9; f++) fp.p[f][first_slot + k] = vals[(size_t)f * count + k];
+    if (hfield) hfield[first_slot + k] = vals[(size_t)9 * count + k];
     orig[first_slot + k] = (int32_t)(n_owned + k);
+}
+
+__global__ __launch_bounds__(256) void set_numbers(int32_t *__restrict__ number, int64_t first, int64_t count,
+                                                   const int64_t *__restrict__ src) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < count) number[first + k] = (int32_t)src[k];
 }
 
 // out[0 .. 3*MAX_SINKS) = my partial sink accelerations, out[3*MAX_SINKS] = my pending dt candidate
@@ -131,13 +139,19 @@ int domain_replace_ghosts(sph_ctx *c, int64_t count, const double *d_vals) {
     if (count > 0) {
         FieldPtrs9 fp{};
         for (int f = 0; f < 9; f++) fp.p[f] = c->f[f];
-        append_ghosts<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->orig, n_old, c->n_owned, count, d_vals);
+        append_ghosts<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->variable ? c->f[SPH_F_H] : nullptr, c->orig, n_old, c->n_owned, count, d_vals);
         DM_CHECK(hipGetLastError());
     }
     c->dead_below = n_old;             // slots below with an original id >= n_owned are the old ghosts
     c->n_slots = n_old + count;
     c->n = c->n_owned + count;
     return SPH_OK;
+}
+
+hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const int64_t *d_numbers) {
+    if (count <= 0) return hipSuccess;
+    set_numbers<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(c->number, first, count, d_numbers);
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_partials(sph_ctx *c, double *d_out) {

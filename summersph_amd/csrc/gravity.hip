@@ -430,7 +430,7 @@ void gravity_free(sph_ctx *c) {
     ctx_free(c, c->g_leafA); ctx_free(c, c->g_walkB); ctx_free(c, c->g_leafB);
     ctx_free(c, c->g_keys); ctx_free(c, c->g_keys_alt); ctx_free(c, c->g_vals); ctx_free(c, c->g_vals_alt);
     ctx_free_ptr(c, c->g_sort_tmp); c->g_sort_tmp = nullptr; c->g_sort_tmp_bytes = 0;
-    c->g_cap = 0;
+    c->g_cap = 0; c->gx_keys_valid = false;
 }
 
 // tree arrays for `need` leaves (the context's slots, or an external source set that may be much larger)
@@ -456,6 +456,27 @@ static int gravity_reserve(sph_ctx *c, int64_t need) {
     return SPH_OK;
 }
 
+// path keys of the external source set, sorted (shared by the gravity tree, the variable-h leaf boxes and accretion)
+int global_keys_sorted(sph_ctx *c) {
+    if (!c->gx_src) { c->err = "no external source set"; return SPH_ERR_STATE; }
+    if (c->gx_keys_valid) return SPH_OK;
+    const int64_t n = c->gx_n;
+    { const int st = gravity_reserve(c, n); if (st != SPH_OK) return st; }
+    RootBox rb;
+    double size = 0.0;
+    for (int a = 0; a < 3; a++) {
+        rb.c[a] = (c->gx_box[3 + a] + c->gx_box[a]) / 2.0;
+        size = std::max(size, c->gx_box[3 + a] - c->gx_box[a]);
+    }
+    rb.size = size;
+    grav_keys<<<dim3((unsigned)((n + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(rb, reinterpret_cast<const double4 *>(c->gx_src), n, c->g_keys, c->g_vals);
+    GR_CHECK2(hipGetLastError());
+    size_t tmp = c->g_sort_tmp_bytes;
+    GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
+    c->gx_keys_valid = true;
+    return SPH_OK;
+}
+
 // builds the tree over the context's own particles (current cell-sorted positions) or over the external source set
 int gravity_tree_build(sph_ctx *c) {
     const bool ext = c->gx_src != nullptr;
@@ -475,10 +496,15 @@ int gravity_tree_build(sph_ctx *c) {
     c->root_box[3] = size;
     const unsigned gb = (unsigned)((n + GB - 1) / GB);
     const double4 *drec = reinterpret_cast<const double4 *>(ext ? c->gx_src : c->drec);
-    grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->g_keys, c->g_vals);
-    GR_CHECK2(hipGetLastError());
-    size_t tmp = c->g_sort_tmp_bytes;
-    GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
+    if (ext) {
+        const int st = global_keys_sorted(c);
+        if (st != SPH_OK) return st;
+    } else {
+        grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->g_keys, c->g_vals);
+        GR_CHECK2(hipGetLastError());
+        size_t tmp = c->g_sort_tmp_bytes;
+        GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
+    }
     TreeArrays t = tree_arrays(c);
     leaf_data<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->g_vals_alt, drec, (int)n, t);
     if (n >= 2) {

@@ -120,6 +120,8 @@ struct sph_ctx {
     int64_t g_cap = 0;                               // leaves the tree arrays hold
     // external gravity sources (multi-GPU: the particles of every GPU), caller-owned {x,y,z,m} records + their bounding box
     const double *gx_src = nullptr; int64_t gx_n = 0; double gx_box[6] = {0, 0, 0, 0, 0, 0};
+    bool gx_keys_valid = false;                      // g_keys_alt / g_vals_alt hold the sorted path keys of gx_src
+    int32_t *number = nullptr; bool numbers_set = false;   // variable h: the reference's particle numbers by original id
 
     // grid
     sph::GridDesc grid{};
@@ -209,6 +211,7 @@ int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6);      // h_out6 != nu
 int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts);
 int domain_replace_ghosts(sph_ctx *c, int64_t count, const double *d_vals);
 hipError_t launch_pack_partials(sph_ctx *c, double *d_out);
+hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const int64_t *d_numbers);
 hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, int stride, bool apply_dt);
 // LDS-tiled fixed-h kernels (tiled.hip; default)
 int nlist_build_tiled(sph_ctx *c);
@@ -217,6 +220,7 @@ hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
 // self-gravity (gravity.hip)
 hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
 int gravity_tree_build(sph_ctx *c);
+int global_keys_sorted(sph_ctx *c);      // sorted path keys of the external source set -> c->g_keys_alt / g_vals_alt
 void gravity_free(sph_ctx *c);
 hipError_t launch_gravity(sph_ctx *c);
 // accretion + boundary cull (accrete.hip)

@@ -126,6 +126,41 @@ __global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t 
     lrec[slot] = make_double4(cx, cy, cz, 2.0 * h + size / 2.0);          // [V]:380,479
 }
 
+// Multi-GPU: the octree is that of ALL GPUs' particles.  gkeys = their sorted path keys (n_glob); a local slot finds its
+// own key there (it is one of them) and takes its leaf level from the neighbours in THAT order.
+__global__ __launch_bounds__(VBLOCK) void leaf_boxes_ext(RootBox rb, const uint64_t *__restrict__ gkeys, int64_t n_glob,
+                                                         int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec) {
+    const int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = prec[i];
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    uint64_t key = 0;
+    for (int l = 0; l < LEVELS; l++) {
+        const int bx = p.x > cx, by = p.y > cy, bz = p.z > cz;
+        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+        const double q = 0.25 * size;
+        cx = cx + (bx ? q : -q); cy = cy + (by ? q : -q); cz = cz + (bz ? q : -q);
+        size = size * 0.5;
+    }
+    int64_t lo = 0, hi = n_glob;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (gkeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    int cp = 0;
+    if (lo > 0) cp = max(cp, common_levels(key, gkeys[lo - 1]));
+    if (lo + 1 < n_glob) cp = max(cp, common_levels(key, gkeys[lo + 1]));
+    const int level = n_glob == 1 ? 0 : min(cp + 1, LEVELS);
+    cx = rb.c[0]; cy = rb.c[1]; cz = rb.c[2]; size = rb.size;
+    for (int l = 1; l <= level; l++) {
+        const int ch = (int)((key >> (3 * (LEVELS - l))) & 7);
+        const double q = 0.25 * size;
+        cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+        size = size * 0.5;
+    }
+    lrec[i] = make_double4(cx, cy, cz, 2.0 * p.w + size / 2.0);          // [V]:380,479
+}
+
 __global__ __launch_bounds__(VBLOCK) void cell_hmax_kernel(const int32_t *__restrict__ cell_start, int64_t ncells,
                                                            const double4 *__restrict__ prec, double *__restrict__ hmax) {
     const int64_t c = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
@@ -163,7 +198,8 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
                                                         int32_t *__restrict__ ncount, int32_t *__restrict__ ntail,
-                                                        int32_t *__restrict__ wave_max, int32_t *__restrict__ flags) {
+                                                        int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
+                                                        const int32_t *__restrict__ number) {
     __shared__ double4 tile[T_NV], tile_l[T_NV];
     __shared__ int32_t tile_o[T_NV];
     __shared__ int s_lo[VBLOCK / WAVE], s_hi[VBLOCK / WAVE];
@@ -173,7 +209,9 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     const bool live = i < n && orig[i] < n_owned;
     const int64_t self = i < n ? i : n - 1;
     const double4 pi = prec[self], li = lrec[self];
-    const int oi = orig[self];
+    // the reference's particle number decides which partner's walk counts for a force pair ([V]:383); on several
+    // GPUs the caller supplies the global numbers (sph_set_numbers_dev), else it is the context's own numbering
+    const int oi = number ? number[orig[self]] : orig[self];
     const double p[3] = {pi.x, pi.y, pi.z};
     int cc[3];
     cell_coords(g, pi.x, pi.y, pi.z, cc);
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
         for (int cb = lo; cb < hiv; cb += T_NV) {
             const int ce = min(cb + T_NV, hiv);
             __syncthreads();
-            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) { tile[t] = prec[cb + t]; tile_l[t] = lrec[cb + t]; tile_o[t] = orig[cb + t]; }
+            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) { tile[t] = prec[cb + t]; tile_l[t] = lrec[cb + t]; tile_o[t] = number ? number[orig[cb + t]] : orig[cb + t]; }
             __syncthreads();
             if (!use2) continue;
             // per-lane walk over this lane's own columns and cells (lanes of different columns advance in
@@ -578,7 +616,7 @@ hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes) {
 }
 
 int varh_h_stats(sph_ctx *c) {
-    const int64_t n = c->n;
+    const int64_t n = std::max(c->n, c->n_slots);     // a pending ghost swap: every occupied slot (an upper bound on h)
     if (n == 0) { c->h_max_glob = c->h_mean = c->p.h; return SPH_OK; }
     const int nb = (int)std::min<int64_t>((n + VBLOCK - 1) / VBLOCK, 512);
     double *part = c->bbox_part;     // reuse the bbox partial buffer (>= 1024*6 doubles)
@@ -608,12 +646,27 @@ int varh_leaf_build(sph_ctx *c) {
     c->root_box[3] = size;
     const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
     const double4 *prec = reinterpret_cast<const double4 *>(c->prec);
-    leaf_keys<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, prec, n, c->mkeys, c->mvals);
-    VH_CHECK(hipGetLastError());
-    size_t tmp = c->msort_tmp_bytes;
-    VH_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
-    leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec));
-    VH_CHECK(hipGetLastError());
+    if (c->gx_src) {
+        // the shared octree: root box and sorted keys of every GPU's particles (gravity.hip keeps them)
+        size = 0.0;
+        for (int a = 0; a < 3; a++) {
+            rb.c[a] = (c->gx_box[3 + a] + c->gx_box[a]) / 2.0;
+            size = std::max(size, c->gx_box[3 + a] - c->gx_box[a]);
+        }
+        rb.size = size;
+        for (int a = 0; a < 3; a++) c->root_box[a] = rb.c[a];
+        c->root_box[3] = size;
+        { const int st = global_keys_sorted(c); if (st != SPH_OK) return st; }
+        leaf_boxes_ext<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->g_keys_alt, c->gx_n, n, prec, reinterpret_cast<double4 *>(c->lrec));
+        VH_CHECK(hipGetLastError());
+    } else {
+        leaf_keys<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, prec, n, c->mkeys, c->mvals);
+        VH_CHECK(hipGetLastError());
+        size_t tmp = c->msort_tmp_bytes;
+        VH_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+        leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec));
+        VH_CHECK(hipGetLastError());
+    }
     cell_hmax_kernel<<<dim3((unsigned)((c->grid.ncells + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
         c->cell_start, c->grid.ncells, prec, c->cell_hmax);
     VH_CHECK(hipGetLastError());
@@ -629,7 +682,8 @@ int varh_nlist_build(sph_ctx *c) {
         VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_v_tiled<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
             c->grid, R, c->h_max_glob, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
-            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->d_flags);
+            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->d_flags,
+            c->numbers_set ? c->number : nullptr);
         VH_CHECK(hipGetLastError());
         VH_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         VH_CHECK(hipStreamSynchronize(c->stream));

@@ -72,8 +72,13 @@ class HipBackend:
     def set_rank(self, rank, nranks):
         self.ctx.set_rank(rank, nranks)
 
+    @property
+    def variable(self) -> bool:
+        return bool(self.ctx.params.flags & self.capi.FLAG_VARIABLE_H)
+
     def upload(self, state: torch.Tensor):
-        """state: [9, n] (rows in STATE order): this rank's owned particles; ghosts come later"""
+        """state: [9, n] (rows in STATE order; a 10th row h with variable smoothing lengths): this rank's owned
+        particles; ghosts come later"""
         state = state.contiguous()
         n = int(state.shape[1])
         self.n_owned = n
@@ -81,6 +86,15 @@ class HipBackend:
             self._reserved = n + n // 4 + 65536
             self.ctx.reserve(self._reserved)
         self.ctx.upload_dev(n, [state[k].data_ptr() for k in range(9)])
+        if self.variable and n:
+            self.ctx.upload_field_dev("h", state[9].data_ptr(), n)
+
+    def set_numbers(self, first: int, numbers: torch.Tensor):
+        numbers = numbers.to(torch.int64).contiguous()
+        self.ctx.set_numbers_dev(first, int(numbers.numel()), numbers.data_ptr())
+
+    def update_h(self):
+        self.ctx.update_h()
 
     def owned_bbox(self) -> torch.Tensor:
         out = torch.empty(6, dtype=torch.float64, device=self.device)
@@ -219,8 +233,13 @@ class DistSim:
         self.migrate_every = max(1, int(migrate_every))
         backend.set_rank(self.rank, self.P)
         n = int(np.asarray(gas["x"]).size)
-        rows = [np.ascontiguousarray(gas[k] if k in gas and gas[k] is not None else np.zeros(n), dtype=np.float64) for k in STATE]
-        self.owned = torch.as_tensor(np.stack(rows), device=self.dev)            # [9, n_owned]; stale once in_backend
+        # variable smoothing lengths ("SUMMER_SPH - Variable.f90"): h travels with the state, ghosts also carry their
+        # global particle number (the pair rule of [V]:383 depends on it) and the octree of ALL particles supplies the
+        # leaf boxes (the all-gathered sources of the self-gravity path)
+        self.variable = bool(getattr(backend, "variable", False))
+        self.fields = STATE + (["h"] if self.variable else [])
+        rows = [np.ascontiguousarray(gas[k] if k in gas and gas[k] is not None else np.zeros(n), dtype=np.float64) for k in self.fields]
+        self.owned = torch.as_tensor(np.stack(rows), device=self.dev)            # [9|10, n_owned]; stale once in_backend
         gid = gas.get("gid")
         self.gid = torch.as_tensor(np.asarray(gid if gid is not None else np.arange(n), dtype=np.int64), device=self.dev)
         self.n_owned = n
@@ -321,7 +340,7 @@ class DistSim:
     # ---- domain bookkeeping -----------------------------------------------------------------------
     def _pull_owned(self):
         """owned state out of the backend: one fused gather of the 9 state fields"""
-        self.owned = self.be.gather(STATE, None, self.n_owned)
+        self.owned = self.be.gather(self.fields, None, self.n_owned)
         self.in_backend = False
 
     def _migrate(self):
@@ -336,25 +355,33 @@ class DistSim:
         self.stats["migrations"] += 1
         if moved == 0:
             return
-        payload = torch.cat([self.owned, self.gid.to(torch.float64)[None, :]])     # [10, n]; gid < 2^53 is exact
+        payload = torch.cat([self.owned, self.gid.to(torch.float64)[None, :]])     # [nf + 1, n]; gid < 2^53 is exact
         send = [None] * self.P
         for q in range(self.P):
             if int(mine_out[q]):
                 send[q] = payload[:, dest == q]
-        recv = self._p2p(send, [int(v) for v in incoming], 10)
+        nf = len(self.fields)
+        recv = self._p2p(send, [int(v) for v in incoming], nf + 1)
         parts = [payload[:, dest == self.rank]] + [r for r in recv if r is not None]
         allp = torch.cat(parts, dim=1)
-        self.owned = allp[:9].contiguous()
-        self.gid = allp[9].to(torch.int64)
+        self.owned = allp[:nf].contiguous()
+        self.gid = allp[nf].to(torch.int64)
         self.n_owned = int(allp.shape[1])
         self.stats["migrated"] += moved
 
     def _exchange_ghosts(self):
         """steps 3-5 of the module docstring: who needs which of my particles, ship them, swap them in"""
         be = self.be
-        boxes = self._all_gather(be.owned_bbox()).cpu().numpy()     # [P, 6] on the host
+        if self.variable:
+            # i and j interact within 2 max(h_i, h_j): the ghost layer is as wide as twice the largest h anywhere
+            hm = be.gather(["h"], None, self.n_owned).max() if self.n_owned else torch.zeros((), dtype=torch.float64, device=self.dev)
+            bh = self._all_gather(torch.cat([be.owned_bbox(), hm.reshape(1)])).cpu().numpy()
+            boxes = np.ascontiguousarray(bh[:, :6])
+            r = 2.0 * float(bh[:, 6].max()) * (1.0 + 1e-9)
+        else:
+            boxes = self._all_gather(be.owned_bbox()).cpu().numpy()     # [P, 6] on the host
+            r = 2.0 * self.h * (1.0 + 1e-9)
         self.boxes = boxes
-        r = 2.0 * self.h * (1.0 + 1e-9)
         me_lo, me_hi = boxes[self.rank, :3], boxes[self.rank, 3:]
         mine_ok = bool(np.all(np.isfinite(boxes[self.rank])))
         peers, sel = [], []
@@ -379,8 +406,13 @@ class DistSim:
         # cannot have a ghost neighbour (their forces do not wait for the ghost fields)
         senders = [q for q in range(self.P) if rc[q] > 0]
         be.set_boundary_boxes(boxes[senders] if senders else np.zeros((0, 6)))
-        send = [be.gather(STATE, idx) if idx is not None else None for idx in self.send_idx]
-        recv = self._p2p(send, rc, 9)
+        nf = len(self.fields)
+        if self.variable:         # + the global particle number of every ghost
+            send = [torch.cat([be.gather(self.fields, idx), self.gid[idx].to(torch.float64)[None, :]]) if idx is not None else None
+                    for idx in self.send_idx]
+        else:
+            send = [be.gather(self.fields, idx) if idx is not None else None for idx in self.send_idx]
+        recv = self._p2p(send, rc, nf + (1 if self.variable else 0))
         first = self.n_owned
         parts = []
         for q in range(self.P):
@@ -393,9 +425,12 @@ class DistSim:
         elif parts:
             ghosts = torch.cat(parts, dim=1)
         else:
-            ghosts = torch.empty((9, 0), dtype=torch.float64, device=self.dev)
+            ghosts = torch.empty((nf + (1 if self.variable else 0), 0), dtype=torch.float64, device=self.dev)
         self.stats["ghosts"] = int(ghosts.shape[1])
-        be.replace_ghosts(ghosts)
+        be.replace_ghosts(ghosts[:nf])
+        if self.variable:
+            be.set_numbers(0, self.gid)
+            be.set_numbers(self.n_owned, ghosts[nf].to(torch.int64))
 
     def _gravity_sources(self):
         """Self-gravity is long range: every rank gets {x, y, z, m} of ALL particles (one all-gather, padded to the
@@ -461,12 +496,12 @@ class DistSim:
             if self.P > 1:
                 with self._phase("ghost_exchange"):
                     self._exchange_ghosts()
-                if self.gravity:
+                if self.gravity or self.variable:
                     with self._phase("gravity_sources"):
                         self._gravity_sources()
             with self._phase("compute"):
                 be.density()
-            pending, tag = (self._refresh_ghost_start(["rho"]) if self.P > 1 else None), "ghost_rho"
+            pending, tag = (self._refresh_ghost_start(["rho", "omega"] if self.variable else ["rho"]) if self.P > 1 else None), "ghost_rho"
         else:
             # the density sum needs positions and masses only: it runs while the ghosts' v, u, alpha travel
             with self._phase("ghost_vel"):
@@ -475,7 +510,7 @@ class DistSim:
             with self._phase("compute"):
                 be.density()
         self.pos_dirty = self.vel_dirty = False
-        if self.P > 1 and not self.gravity:
+        if self.P > 1 and not self.gravity and not self.variable:
             # ... and so do the forces of the particles that cannot see a ghost; the rest follows once the ghost
             # fields have arrived and the EOS of the ghosts is refreshed
             with self._phase("compute"):
@@ -512,6 +547,11 @@ class DistSim:
             be.dt_candidate_local()          # get_next_timestep's local part, [F]:845-851; reduced with the next exchange
         self.vel_dirty = True
         self.dt_pending = True
+        if self.variable:
+            with self._phase("compute"):
+                be.update_h()                # calc_smoothing, [V]:1152; the ghosts' h is stale now: full exchange next
+            self.pos_dirty = True
+            self.vel_dirty = False
         if self.accrete and self.P > 1:
             with self._phase("accrete"):
                 self._accrete_and_cull()
