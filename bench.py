@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--no-tiles", action="store_true", help="SPH_FLAG_NO_LDS_TILES: per-lane-gather list build (A/B)")
     ap.add_argument("--tile-eval", action="store_true", help="SPH_FLAG_LDS_TILE_EVAL: LDS-staged density/forces (A/B)")
     ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
-                    help="headline workload; variable is single-GPU only")
+                    help="headline workload: [F] fixed h (default) or [V] per-particle h")
     ap.add_argument("--ic", default="disc", choices=["disc", "ring"], help="fixed-h workload: the uniform disc (headline) or "
                     "BASELINE configs[3]'s thin ring r ~ N(r0, 0.05 r0) (artificial viscosity at work)")
     ap.add_argument("--self-gravity", action="store_true", help="SPH_FLAG_SELF_GRAVITY in the headline run (NOT the "
@@ -187,9 +187,6 @@ def main():
     if args.full_simulate:
         args.self_gravity = True
     variable = args.mode == "variable"
-    if variable and world > 1:
-        raise SystemExit("the variable-h path is single-GPU this round (its octree leaf boxes need the global particle "
-                         "set); use --mode fixed for --gpus > 1")
     flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
         | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0) \
         | (capi.FLAG_ACCRETE_CULL if args.full_simulate else 0)
@@ -204,15 +201,16 @@ def main():
         # weak scaling: the disc holds n x world particles (same surface density, larger radius); every rank
         # owns one equal-count x-slab of it
         from summersph_amd.dist import DistSim, HipBackend, slab_bounds
-        rows = (ic.thin_ring(args.n * world, seed=404) if args.ic == "ring"
-                else ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb))
+        rows = ic.keplerian_disc_var(args.n * world, seed=303) if variable else (
+            ic.thin_ring(args.n * world, seed=404) if args.ic == "ring"
+            else ic.keplerian_disc(args.n * world, seed=202, nngb=args.nngb))
         gas, sinks = ic.split_rows(rows)
         bounds = slab_bounds(gas["x"], world)
         sel = np.searchsorted(bounds, gas["x"], side="right") == rank
         mine = {k: v[sel] for k, v in gas.items()}
         mine["gid"] = np.nonzero(sel)[0]
         del rows, gas
-        be = HipBackend(local_rank, flags=flags)
+        be = HipBackend(local_rank, variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable else HipBackend(local_rank, flags=flags)
         # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
         sim = DistSim(be, mine, sinks, bounds, group=None, comm_device=None if args.backend == "nccl" else "cpu")
         ctx = be.ctx
