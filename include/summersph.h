@@ -224,7 +224,9 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     (sph_run's mechanism), so that a step needs no host round trip for them.
  * sph_dt_candidate_dev    local dt candidate ([F]:845-851 over owned particles) kept on the device.
  * sph_pack_partials_dev   d_out[0..3*64) = this GPU's partial sink accelerations (ax[64] ay[64]
- *                     az[64]), d_out[192] = its dt candidate: SPH_PARTIALS doubles, to be
+ *                     az[64]), d_out[192] = its dt candidate, d_out[193..199) = the bounding box its owned particles
+ *                     will have after the coming kick + drift (union over the three dt values the dt rule can
+ *                     produce; NaN when the rates are stale): SPH_PARTIALS doubles, to be
  *                     all-gathered by the caller.
  * sph_apply_partials_dev  sink accelerations = sum over the nranks gathered blocks (rank order);
  *                     apply_dt != 0: t += dt, then [F]:855-858 with the minimum candidate.
@@ -253,7 +255,7 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     ones, for owned particles and ghosts alike.  Without this call: the context's own numbering.
  *                     With SPH_FLAG_VARIABLE_H sph_replace_ghosts_dev takes 10 rows (.. alpha, h) and
  *                     sph_set_gravity_sources_dev also supplies the octree the leaf boxes are taken from.            */
-#define SPH_PARTIALS 193
+#define SPH_PARTIALS 199
 int sph_set_numbers_dev(sph_ctx *ctx, int64_t first, int64_t count, const int64_t *d_numbers);
 #define SPH_ACC_PARTIALS 448
 int sph_accrete_mark_dev(sph_ctx *ctx, int64_t src_offset, double *d_partials);

@@ -59,6 +59,56 @@ __global__ void pack_partials(const double *__restrict__ sink, const double *__r
     if (k == 3 * MAX_SINKS) out[k] = dtbuf[2];
 }
 
+// Where will my particles be after the coming kick + drift?  x' = x + (v + a dt'/2) dt' with dt' one of the three values
+// the dt rule can produce (0.5, 1, 1.5 times the current dt): the union of the three boxes contains the box after the
+// drift, so the other GPUs can pick my ghosts without another exchange of bounding boxes.
+constexpr int PB_BLOCKS = 512;
+__global__ __launch_bounds__(256) void pred_bbox_partial(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, const double *__restrict__ vx,
+                                                         const double *__restrict__ vy, const double *__restrict__ vz,
+                                                         const double *__restrict__ ax, const double *__restrict__ ay,
+                                                         const double *__restrict__ az, const int32_t *__restrict__ orig,
+                                                         int32_t n_owned, int64_t n, const double *__restrict__ dtbuf,
+                                                         double *__restrict__ part) {
+    __shared__ double sm[6][4];
+    const double dt0 = dtbuf[0];
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (orig[i] >= n_owned) continue;
+        const double p[3] = {x[i], y[i], z[i]}, v[3] = {vx[i], vy[i], vz[i]}, a[3] = {ax[i], ay[i], az[i]};
+#pragma unroll
+        for (int f = 1; f <= 3; f++) {
+            const double dt = 0.5 * f * dt0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double q = p[k] + (v[k] + 0.5 * a[k] * dt) * dt;
+                lo[k] = fmin(lo[k], q); hi[k] = fmax(hi[k], q);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double mn = lo[k], mx = hi[k];
+        for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
+        if (lane == 0) { sm[k][wv] = mn; sm[3 + k][wv] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int w = 1; w < 4; w++) r = threadIdx.x < 3 ? fmin(r, sm[threadIdx.x][w]) : fmax(r, sm[threadIdx.x][w]);
+        part[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
+__global__ void pred_bbox_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    double r = k < 3 ? INFINITY : -INFINITY;
+    for (int b = 0; b < nb; b++) r = k < 3 ? fmin(r, part[(size_t)b * 6 + k]) : fmax(r, part[(size_t)b * 6 + k]);
+    out[k] = r;
+}
+
 // sink accelerations = sum over ranks (rank order); optionally get_next_timestep's rule ([F]:851-859, t = t + dt of
 // [F]:914 first) with the minimum of the ranks' candidates
 __global__ void apply_partials(const double *__restrict__ all, int nranks, int stride, double *__restrict__ sink,
@@ -156,6 +206,16 @@ hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const in
 
 hipError_t launch_pack_partials(sph_ctx *c, double *d_out) {
     pack_partials<<<dim3(1), dim3(256), 0, c->stream>>>(c->sink, c->d_dt, d_out);
+    // [193, 199): the predicted bounding box of the owned particles after the coming drift (needs current rates)
+    if (c->rates_valid && c->n_slots == c->n) {
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->n + 255) / 256, PB_BLOCKS));
+        pred_bbox_partial<<<dim3(nb), dim3(256), 0, c->stream>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->f[SPH_F_VX], c->f[SPH_F_VY],
+                                                                 c->f[SPH_F_VZ], c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
+                                                                 (int32_t)c->n_owned, c->n, c->d_dt, c->bbox_part);
+        pred_bbox_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->bbox_part, nb, d_out + 3 * MAX_SINKS + 1);
+    } else {
+        (void)hipMemsetAsync(d_out + 3 * MAX_SINKS + 1, 0xff, 6 * sizeof(double), c->stream);      // NaN: no prediction
+    }
     return hipGetLastError();
 }
 

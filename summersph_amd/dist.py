@@ -8,17 +8,19 @@ the GPU context; per step (= the reference's loop body, [F]:889-916) the ranks e
   start of step (positions as at the end of the last step)
     1. point-to-point: v, u, alpha of the ghosts (their owners kicked them)
        density + EOS + forces
-    2. all-gather [193 doubles/rank]: partial sink accelerations, and the dt candidate left by the
-       previous step -> summed / min-reduced on the device in rank order, dt rule [F]:855-858
+    2. all-gather [199 doubles/rank]: partial sink accelerations, the dt candidate left by the previous
+       step -> summed / min-reduced on the device in rank order, dt rule [F]:855-858; and every rank's
+       PREDICTED bounding box after the coming kick + drift
   kick, drift
   end of step (positions changed)
-    3. all-gather: bounding boxes of the owned particles          (host: which peers overlap)
+    3. (only on migration steps and for the octree paths) all-gather: bounding boxes of the owned particles;
+       otherwise the boxes predicted in 2. are used (supersets: a few ghosts too many, never one too few)
     4. all-gather: how many particles each rank sends to each peer (host: message sizes)
     5. point-to-point: the 9 state fields of the particles inside (peer box + 2h); they replace the
        ghost slots of the context (sph_replace_ghosts_dev)
        density of the owned particles
     6. point-to-point: rho of the same particles -> ghost rho; EOS, forces
-    7. all-gather [193 doubles/rank]: partial sink accelerations
+    7. all-gather [199 doubles/rank]: partial sink accelerations
   kick; the local dt candidate stays on the device until 2. of the next step.
 
 With SPH_FLAG_SELF_GRAVITY every rank additionally all-gathers {x, y, z, m} of all particles after a drift and builds
@@ -44,7 +46,8 @@ import torch
 import torch.distributed as dist
 
 STATE = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha"]
-PARTIALS = 193          # SPH_PARTIALS: ax[64] ay[64] az[64] of the sinks + the dt candidate
+PARTIALS = 199          # SPH_PARTIALS: ax[64] ay[64] az[64] of the sinks, the dt candidate, the predicted bounding box
+DT_SLOT = 192           # position of the dt candidate in that vector
 ACC_PARTIALS = 448      # SPH_ACC_PARTIALS: per sink m, m x, m y, m z, m vx, m vy, m vz of the accreted particles
 
 
@@ -264,6 +267,8 @@ class DistSim:
         self.stats_removed = 0
         self.counts_all = None    # owned particles of every rank (changes with migrations only)
         self.boxes = None         # every rank's owned bounding box at the last ghost exchange (host)
+        self._pred, self._pred_event, self._pred_pinned = None, None, None
+        self.pred_for_drift = False   # the boxes predicted at the last reduction describe the positions after the drift just done
         self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
         self.phase_s = {}
         self._gather_into = True  # all_gather_into_tensor until the backend refuses it
@@ -372,7 +377,18 @@ class DistSim:
     def _exchange_ghosts(self):
         """steps 3-5 of the module docstring: who needs which of my particles, ship them, swap them in"""
         be = self.be
-        if self.variable:
+        use_pred = self.pred_for_drift and self._pred is not None and not (self.gravity or self.variable)
+        self.pred_for_drift = False
+        if use_pred:
+            if self._pred_event is not None:
+                self._pred_event.synchronize()
+            boxes = np.array(self._pred.numpy(), dtype=np.float64, copy=True)
+            use_pred = bool(np.all(np.isfinite(boxes) | np.isinf(boxes)))     # NaN rows: some rank had no prediction
+        if use_pred:
+            # supersets of the true boxes: a few ghosts too many, never one too few; the octree paths (self-gravity,
+            # variable h) need the exact global box and take the exchange below instead
+            r = 2.0 * self.h * (1.0 + 1e-9)
+        elif self.variable:
             # i and j interact within 2 max(h_i, h_j): the ghost layer is as wide as twice the largest h anywhere
             hm = be.gather(["h"], None, self.n_owned).max() if self.n_owned else torch.zeros((), dtype=torch.float64, device=self.dev)
             bh = self._all_gather(torch.cat([be.owned_bbox(), hm.reshape(1)])).cpu().numpy()
@@ -471,10 +487,23 @@ class DistSim:
         self._refresh_ghost_finish(self._refresh_ghost_start(names))
 
     def _reduce(self):
-        """sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied"""
-        allp = self._all_gather(self.be.pack_partials()).to(self.dev)
+        """sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied.  The same
+        message carries every rank's PREDICTED bounding box after the coming kick + drift (the rates are known now), so
+        that the ghost exchange that follows the drift needs no exchange of bounding boxes of its own."""
+        allc = self._all_gather(self.be.pack_partials())
+        allp = allc.to(self.dev)
         self.be.apply_partials(allp, self.dt_pending)
         self.dt_pending = False
+        pred = allc[:, DT_SLOT + 1:DT_SLOT + 7]
+        if pred.device.type == "cpu":
+            self._pred, self._pred_event = pred.clone(), None
+        else:                                   # to the host without stalling the stream: read after the drift
+            if self._pred_pinned is None:
+                self._pred_pinned = torch.empty((self.P, 6), dtype=torch.float64, pin_memory=True)
+            self._pred_pinned.copy_(pred, non_blocking=True)
+            self._pred_event = torch.cuda.Event()
+            self._pred_event.record()
+            self._pred = self._pred_pinned
 
     # ---- the hot path, distributed -----------------------------------------------------------------
     def evaluate(self):
@@ -489,6 +518,7 @@ class DistSim:
                     with self._phase("migrate"):
                         self._migrate()
                     self.since_migrate = 0
+                    self.pred_for_drift = False      # ownership changed: the predicted boxes are void
                 with self._phase("upload"):
                     be.upload(self.owned)
                 self.in_backend = True
@@ -540,6 +570,7 @@ class DistSim:
             be.kick()
             be.drift()
         self.pos_dirty = True
+        self.pred_for_drift = True       # the reduction of the evaluation above predicted where this drift takes everybody
         self.since_migrate += 1
         self.evaluate()
         with self._phase("compute"):
@@ -580,7 +611,7 @@ class DistSim:
             # the sink accelerations in the blocks are the totals every rank already holds: keep them
             # (summing them again would multiply by P), only the dt part of the blocks is applied
             mine = allp[self.rank:self.rank + 1].clone()
-            mine[0, PARTIALS - 1] = allp[:, PARTIALS - 1].min()
+            mine[0, DT_SLOT] = allp[:, DT_SLOT].min()
             self.be.apply_partials(mine, True)
             self.dt_pending = False
 

@@ -101,11 +101,21 @@ class OracleBackend:
         self.cand = self._dt_candidate()
 
     def pack_partials(self):
-        out = np.zeros(193)
+        out = np.zeros(199)
         ns = self.s["x"].size
         for k, a in enumerate(("ax", "ay", "az")):
             out[64 * k:64 * k + ns] = self.s[a]
         out[192] = self.cand
+        # predicted bounding box of the owned particles after the coming kick + drift, for the three possible dt
+        f, o = self.f, self.n_owned
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        for fac in (0.5, 1.0, 1.5):
+            dt = fac * self.dt
+            for k, (x, v, a) in enumerate((("x", "vx", "ax"), ("y", "vy", "ay"), ("z", "vz", "az"))):
+                q = f[x][:o] + (f[v][:o] + 0.5 * f[a][:o] * dt) * dt
+                if o:
+                    lo[k], hi[k] = min(lo[k], q.min()), max(hi[k], q.max())
+        out[193:196], out[196:199] = lo, hi
         return torch.from_numpy(out)
 
     def apply_partials(self, allp, apply_dt):

@@ -131,7 +131,7 @@ def test_rank_reduction_and_device_dt(capi, torch):
     part = ctx.get_sinks()
     ctx.set_dt(0.01, 2.0)
     ctx.dt_candidate_dev()
-    mine = torch.empty(193, dtype=torch.float64, device="cuda")
+    mine = torch.empty(199, dtype=torch.float64, device="cuda")     # SPH_PARTIALS
     ctx.pack_partials_dev(mine.data_ptr())
     ctx.synchronize()
     m = mine.cpu().numpy()
@@ -142,7 +142,11 @@ def test_rank_reduction_and_device_dt(capi, torch):
     allp[1, 192] = 10.0 * m[192]; allp[2, 192] = 0.004      # < 0.5 dt: the step halves ([F]:857-858)
     dev = torch.from_numpy(allp).cuda()
     torch.cuda.synchronize()
-    ctx.apply_partials_dev(dev.data_ptr(), 3, 193, True)
+    # [193, 199): where the particles will be after the coming kick + drift, for dt' in {0.5, 1, 1.5} dt
+    a = {k: ctx.field(k) for k in "x vx ax".split()}
+    q = np.stack([a["x"] + (a["vx"] + 0.5 * a["ax"] * f * 0.01) * f * 0.01 for f in (0.5, 1.0, 1.5)])
+    assert abs(m[193] - q.min()) <= 1e-12 and abs(m[196] - q.max()) <= 1e-12
+    ctx.apply_partials_dev(dev.data_ptr(), 3, 199, True)
     s = ctx.get_sinks()
     assert s["ax"][0] == (m[0] + 2.0 * m[0]) + -0.5 * m[0]       # rank order
     dt, t = ctx.get_dt()
