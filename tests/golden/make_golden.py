@@ -16,6 +16,9 @@ Fixtures written (numpy .npz, float64, no pickles):
   disc3000_traj.npz     steps 1, 5 (sph), step 5 (full), dt sequences
   disc3000_long.npz     step 40 (sph), dt sequence of 40 steps
   disc3000ns_eval.npz   the same disc without its sink row (dummy-sink path)
+  acc2000_traj.npz      simulate() as it is, 3 steps: 3 particles accreted, 3 culled... (full variant)
+  bin2000_eval/_traj    circumbinary disc, TWO sinks (sink-sink forces, two accretors): one evaluation, and the
+                        full loop for 3 steps
 "eval" files hold both the `sph_*` rates (zero_rates + sink_gravforces + get_SPH, i.e.
 find_forces without Barnes-Hut gas self-gravity) and the `full_*` rates (find_forces as is).
 """
@@ -65,6 +68,30 @@ def keep_steps(rec, steps, extra=("dt_seq", "n_seq", "t_end")):
     return keep
 
 
+def binary_ic():
+    """circumbinary disc: 2000 gas particles (inner edge inside the sinks' reach) + two sinks of 0.6 and 0.4 on a circular
+    orbit of separation 6 around the origin"""
+    rows = ic.keplerian_disc(2000, seed=707, r_in=2.0, nngb=30.0)[:-1]
+    G = 39.478416442871094
+    m1, m2, a = 0.6, 0.4, 6.0
+    w = np.sqrt(G * (m1 + m2) / a ** 3)
+    x1, x2 = a * m2 / (m1 + m2), -a * m1 / (m1 + m2)
+    s = np.zeros((2, 8))
+    s[0, :8] = [x1, 0.0, 0.0, 0.0, w * x1, 0.0, 0.0, m1]
+    s[1, :8] = [x2, 0.0, 0.0, 0.0, w * x2, 0.0, 0.0, m2]
+    return np.vstack([rows[:700], s[:1], rows[700:], s[1:]])       # sink rows anywhere in the file
+
+
+def binary_fixture(td):
+    b = binary_ic()
+    p = os.path.join(td, "bin.txt"); txtio.write_ic(p, b)
+    np.savez(os.path.join(HERE, "bin2000_eval.npz"), ic=b, **run("eval", p))
+    t_b = keep_steps(run("traj", p, 3, "full"), {1, 3})
+    t_s = keep_steps(run("traj", p, 3, "sph"), {3})
+    np.savez(os.path.join(HERE, "bin2000_traj.npz"), ic=b, **{"full_" + k: v for k, v in t_b.items()},
+             **{"sph_" + k: v for k, v in t_s.items()})
+
+
 def main():
     if not os.path.exists(DRIVER):
         sys.exit("oracle/_ref/ref_driver missing: run oracle/build_ref.sh first (build container only)")
@@ -112,6 +139,7 @@ def main():
         p = os.path.join(td, "acc.txt"); txtio.write_ic(p, acc)
         t_a = keep_steps(run("traj", p, 3, "full"), {1, 2, 3})
         np.savez(os.path.join(HERE, "acc2000_traj.npz"), ic=acc, **{"full_" + k: v for k, v in t_a.items()})
+        binary_fixture(td)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):
             print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")

@@ -145,3 +145,14 @@ def test_accretion_and_cull_across_ranks_vs_reference_fixture(tmp_path):
         assert np.array_equal(p["sm"], parts[0]["sm"]) and np.array_equal(p["svx"], parts[0]["svx"])
     for f in FIELDS:
         assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-11, f
+
+
+def test_two_sinks_across_ranks(tmp_path):
+    """a binary: the sink-sink terms are added once (rank 0), the gas terms summed over ranks"""
+    g = load_golden("bin2000_traj")
+    parts, merged = _run(3, 3, g["ic"], tmp_path, migrate_every=2)
+    for p in parts:
+        assert list(p["dts"]) == list(g["sph_dt_seq"])
+        assert np.max(np.abs(p["sx"] - g["sph_s3_sx"])) <= 1e-12 and np.array_equal(p["svx"], parts[0]["svx"])
+    for f in FIELDS:
+        assert rel_err(merged[f], g["sph_s3_" + f]) <= 1e-11, f

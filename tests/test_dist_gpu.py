@@ -162,3 +162,17 @@ def test_hip_variable_h_across_ranks(tmp_path, variant):
     for f in FIELDS + ["h"]:
         merged = np.concatenate([p[f] for p in parts])[order]
         assert rel_err(merged, g[f"{variant}_s5_" + f]) <= 1e-10, f
+
+
+def test_hip_two_sinks_full_loop_across_ranks(tmp_path):
+    """circumbinary disc on 2 ranks, simulate() as it is: sink-sink forces, shared-tree gravity, two accretors"""
+    g = load_golden("bin2000_traj")
+    mp.spawn(_worker_acc, args=(2, _free_port(), 3, str(tmp_path), g["ic"]), nprocs=2, join=True)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    assert list(parts[0]["ns"] + parts[1]["ns"]) == [int(v) for v in g["full_n_seq"][1:]]
+    order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert np.max(np.abs(p["sm"] - g["full_s3_sm"])) <= 1e-15 and np.max(np.abs(p["sx"] - g["full_s3_sx"])) <= 1e-12
+    for f in FIELDS:
+        assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-11, f

@@ -23,7 +23,7 @@ def make_ctx(capi, rows, **kw):
     return ctx, gas, sinks
 
 
-@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval"])
+@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval", "bin2000_eval"])
 def test_find_forces_with_gravity_vs_reference_fixture(capi, name):
     g = load_golden(name)
     ctx, gas, sinks = make_ctx(capi, g["ic"], flags=capi.FLAG_SELF_GRAVITY)
@@ -103,4 +103,37 @@ def test_accrete_explicit_call_and_order(capi):
     assert np.array_equal(gas["x"][keep], x_new)
     ctx.density(); ctx.forces()          # the shrunken set evaluates fine
     assert np.all(np.isfinite(ctx.field("ax")))
+    ctx.close()
+
+
+def test_binary_two_sinks_full_loop(capi):
+    """two sinks: sink-sink forces and two accretors, simulate()'s loop body for 3 steps against the real reference"""
+    g = load_golden("bin2000_traj")
+    ctx, gas, sinks = make_ctx(capi, g["ic"], flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    dts, t, ns = [1e-2], 0.0, [ctx.n]
+    for k in range(1, 4):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt); ns.append(ctx.n)
+        if k in (1, 3):
+            p = f"full_s{k}_"
+            assert ctx.n == g[p + "x"].size
+            for f in "x y z vx vy vz u m alpha".split():
+                assert rel_err(ctx.field(f), g[p + f]) <= 1e-11, (k, f)
+            s = ctx.get_sinks()
+            assert np.max(np.abs(s["m"] - g[p + "sm"])) <= 1e-15 and np.max(np.abs(s["x"] - g[p + "sx"])) <= 1e-12
+            assert np.max(np.abs(s["vy"] - g[p + "svy"])) <= 1e-12
+    assert ns == [int(v) for v in g["full_n_seq"]]
+    assert dts == list(g["full_dt_seq"])
+    ctx.close()
+    # and without self-gravity / accretion
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    dts, t = [1e-2], 0.0
+    for _ in range(3):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt)
+    assert dts == list(g["sph_dt_seq"])
+    for f in "x y z vx vy vz u alpha".split():
+        assert rel_err(ctx.field(f), g["sph_s3_" + f]) <= 1e-11, f
+    s = ctx.get_sinks()
+    assert np.max(np.abs(s["x"] - g["sph_s3_sx"])) <= 1e-12 and np.max(np.abs(s["vy"] - g["sph_s3_svy"])) <= 1e-12
     ctx.close()

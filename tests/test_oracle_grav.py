@@ -14,7 +14,7 @@ def _oracle(g, nthreads=1):
     return orc_grav.OracleFull(gas, sinks, nthreads=nthreads)
 
 
-@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval"])
+@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval", "bin2000_eval"])
 def test_find_forces_with_self_gravity(name):
     g = load_golden(name)
     o = _oracle(g)
@@ -66,4 +66,22 @@ def test_accretion_and_cull():
             assert rel_err(getattr(o, f), g[p + f]) <= 1e-11, (k, f)
         assert np.max(np.abs(o.sm - g[p + "sm"])) <= 1e-15 and np.max(np.abs(o.sx - g[p + "sx"])) <= 1e-12
     assert ns == [int(v) for v in g["full_n_seq"]] and ns[1] < ns[0]
+    assert dts == list(g["full_dt_seq"])
+
+
+def test_binary_two_sinks_full_loop():
+    """two sinks (sink-sink forces, either may accrete): the reference's loop body for 3 steps, and its sph variant"""
+    g = load_golden("bin2000_traj")
+    o = _oracle(g)
+    dts, ns = [1e-2], [o.n]
+    for k in range(1, 4):
+        dts.append(o.step(dts[-1])); ns.append(o.n)
+        if k in (1, 3):
+            p = f"full_s{k}_"
+            assert o.n == g[p + "x"].size
+            for f in "x y z vx vy vz u m alpha".split():
+                assert rel_err(getattr(o, f), g[p + f]) <= 1e-11, (k, f)
+            assert np.max(np.abs(o.sm - g[p + "sm"])) <= 1e-15 and np.max(np.abs(o.sx - g[p + "sx"])) <= 1e-12
+            assert np.max(np.abs(o.svy - g[p + "svy"])) <= 1e-12
+    assert ns == [int(v) for v in g["full_n_seq"]] and ns[-1] == 1997
     assert dts == list(g["full_dt_seq"])

@@ -36,7 +36,7 @@ def make_ctx(capi, rows, **kw):
     return ctx, gas, sinks
 
 
-@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval"])
+@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "disc3000ns_eval", "bin2000_eval"])
 def test_single_evaluation_vs_reference_fixture(capi, name):
     g = load_golden(name)
     ctx, gas, sinks = make_ctx(capi, g["ic"])
