@@ -80,6 +80,8 @@ typedef struct sph_params {
                                    [F]:249-290, 825): sph_forces then equals find_forces as it is.  Single GPU. */
 #define SPH_FLAG_ACCRETE_CULL 32 /* sph_step / sph_run also do the end-of-step sink accretion and boundary cull
                                    of simulate() ([F]:919-920): the particle count may shrink (sph_count) */
+#define SPH_FLAG_SINK_CREATION 64 /* variable h: sph_step / sph_run also run check_sink_creation ([V]:549-597, 1155): the
+                                    number of sinks may grow by one per step (sph_sink_count)                  */
 #define SPH_FLAG_NO_LDS_TILES 4  /* fixed-h path: build the neighbour list with per-lane gathers (pairs.hip)
                                    instead of LDS-staged tiles (tiled.hip); A/B measurements        */
 #define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
@@ -153,7 +155,13 @@ int sph_get_sinks(sph_ctx *ctx, int32_t ns, double *sx, double *sy, double *sz,
 /* accretion radii of the sinks ([F]:694: 3.5, [V]:830: 5.0 for file sinks, 0 for the dummy sink); the
  * defaults set by sph_set_sinks are 3.5 (fixed h) / 5.0 (variable h) */
 int sph_set_sink_radii(sph_ctx *ctx, int32_t ns, const double *radius);
+int sph_get_sink_radii(sph_ctx *ctx, int32_t ns, double *radius);
 int64_t sph_count(const sph_ctx *ctx);
+int32_t sph_sink_count(const sph_ctx *ctx);
+/* check_sink_creation of the variable-h reference ([V]:549-597) on the sorted order of the last sph_density: the first
+ * particle (caller's order) with m (eta/h)^3 > 0.5 either lies within radius + 2h of a sink (nothing happens) or a
+ * sink of mass 1e-11 and radius 2h is created at its position; *created = 0/1 */
+int sph_check_sink_creation(sph_ctx *ctx, int32_t *created);
 /* one field in the caller's particle order, host or device source (e.g. SPH_F_H after sph_upload) */
 int sph_upload_field(sph_ctx *ctx, int field, const double *host, int64_t n);
 int sph_upload_field_dev(sph_ctx *ctx, int field, const double *d_vals, int64_t n);

@@ -23,13 +23,14 @@ FLAG_NO_LDS_TILES = 4
 FLAG_LDS_TILE_EVAL = 8
 FLAG_SELF_GRAVITY = 16
 FLAG_ACCRETE_CULL = 32
+FLAG_SINK_CREATION = 64
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
     "sph_set_sink_radii", "sph_accrete_and_cull",
     "sph_params_default", "sph_params_default_variable", "sph_upload_field", "sph_upload_field_dev", "sph_update_h",
     "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
-    "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count",
+    "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count", "sph_sink_count", "sph_check_sink_creation", "sph_get_sink_radii",
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
@@ -88,6 +89,10 @@ def load():
     lib.sph_last_error.argtypes = [C.c_void_p]
     lib.sph_count.restype = C.c_int64
     lib.sph_count.argtypes = [C.c_void_p]
+    lib.sph_sink_count.restype = C.c_int32
+    lib.sph_sink_count.argtypes = [C.c_void_p]
+    lib.sph_check_sink_creation.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.sph_get_sink_radii.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.sph_stream.restype = C.c_void_p
     lib.sph_stream.argtypes = [C.c_void_p]
     lib.sph_ctx_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
@@ -232,10 +237,17 @@ class Context:
         return int(r.value)
 
     def get_sinks(self) -> dict:
-        ns = self.ns
+        ns = self.ns = int(self.lib.sph_sink_count(self._h))      # check_sink_creation may have added one
         out = {k: np.zeros(ns) for k in "x y z vx vy vz m ax ay az".split()}
         self._ck(self.lib.sph_get_sinks(self._h, ns, *[_hp(out[k]) for k in "x y z vx vy vz m ax ay az".split()]))
+        out["radius"] = np.zeros(ns)
+        self._ck(self.lib.sph_get_sink_radii(self._h, ns, _hp(out["radius"])))
         return out
+
+    def check_sink_creation(self) -> bool:
+        cr = C.c_int32(0)
+        self._ck(self.lib.sph_check_sink_creation(self._h, C.byref(cr)))
+        return bool(cr.value)
 
     # ---- hot path ------------------------------------------------------------------------
     def density(self):

@@ -312,6 +312,62 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     return SPH_OK;
 }
 
+// ---- check_sink_creation, [V]:549-597 -------------------------------------------------------------------------------
+// The FIRST particle (caller's order) with m (eta/h)^3 > 0.5 decides: if it lies within radius_j + 2h of an existing
+// sink nothing happens at all (the reference returns), else a sink of mass 1e-11 and radius 2h is created at its
+// position with its velocity (the particle stays).  At most one sink per call.
+__global__ __launch_bounds__(AB) void sink_create_scan(const double4 *__restrict__ drec, const double *__restrict__ h,
+                                                       const int32_t *__restrict__ orig, int64_t n, int32_t n_owned, double eta,
+                                                       int32_t *__restrict__ first_id) {
+    const int64_t i = (int64_t)blockIdx.x * AB + threadIdx.x;
+    if (i >= n || orig[i] >= n_owned) return;
+    const double t = eta / h[i];
+    if (drec[i].w * (t * t * t) > 0.5) atomicMin(first_id, orig[i]);          // [V]:560
+}
+
+__global__ void sink_create_apply(const int32_t *__restrict__ first_id, const int32_t *__restrict__ inv,
+                                  const double4 *__restrict__ drec, const double *__restrict__ h, const double *__restrict__ vx,
+                                  const double *__restrict__ vy, const double *__restrict__ vz, int ns, double *__restrict__ sink,
+                                  double *__restrict__ srad, int32_t *__restrict__ created) {
+    if (threadIdx.x != 0) return;
+    *created = 0;
+    const int32_t id = *first_id;
+    if (id == 0x7fffffff || ns >= MAX_SINKS) return;
+    const int32_t s = inv[id];
+    const double4 p = drec[s];
+    const double hi = h[s];
+    for (int j = 0; j < ns; j++) {
+        const double d0 = sink[0 * MAX_SINKS + j] - p.x, d1 = sink[1 * MAX_SINKS + j] - p.y, d2 = sink[2 * MAX_SINKS + j] - p.z;
+        const double dr = sqrt(d0 * d0 + d1 * d1 + d2 * d2);                      // [V]:562
+        if (dr < srad[j] + 2 * hi) return;                                        // [V]:563-565
+    }
+    sink[0 * MAX_SINKS + ns] = p.x; sink[1 * MAX_SINKS + ns] = p.y; sink[2 * MAX_SINKS + ns] = p.z;
+    sink[3 * MAX_SINKS + ns] = vx[s]; sink[4 * MAX_SINKS + ns] = vy[s]; sink[5 * MAX_SINKS + ns] = vz[s];
+    sink[6 * MAX_SINKS + ns] = 0.00000000001;                                     // [V]:581
+    sink[7 * MAX_SINKS + ns] = 0.0; sink[8 * MAX_SINKS + ns] = 0.0; sink[9 * MAX_SINKS + ns] = 0.0;
+    srad[ns] = 2 * hi;                                                            // [V]:582
+    *created = 1;
+}
+
+int sink_creation(sph_ctx *c, int32_t *created) {
+    *created = 0;
+    if (!c->variable || c->n == 0) return SPH_OK;
+    if (!c->order_valid) { c->err = "sink creation: needs the sorted order of the current positions"; return SPH_ERR_STATE; }
+    const int32_t big = 0x7fffffff;
+    AC_CHECK(hipMemcpyAsync(c->d_flags + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    sink_create_scan<<<dim3((unsigned)((c->n + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(
+        reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_H], c->orig, c->n, (int32_t)c->n_owned, c->p.eta, c->d_flags + 3);
+    sink_create_apply<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_flags + 3, c->inv, reinterpret_cast<const double4 *>(c->drec),
+                                                           c->f[SPH_F_H], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->ns, c->sink,
+                                                           c->sink_radius, c->d_flags + 2);
+    AC_CHECK(hipGetLastError());
+    int32_t flag = 0;
+    AC_CHECK(hipMemcpyAsync(&flag, c->d_flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    if (flag) { c->ns += 1; *created = 1; c->rates_valid = false; }
+    return SPH_OK;
+}
+
 // ---- multi-GPU: mark + per-rank sums, then (after the caller all-gathered the sums) sink update + compaction ----------
 int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
     if (!c->gx_src) { c->err = "sph_accrete_mark_dev: needs the all-gathered sources (sph_set_gravity_sources_dev)"; return SPH_ERR_STATE; }

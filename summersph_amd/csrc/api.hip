@@ -282,6 +282,10 @@ int one_step_device_dt(sph_ctx *c) {
     API_TRY(do_kick(c, 0.0, true));
     { Timed t(c, SPH_K_DT); API_HIP(launch_next_dt(c, true)); }
     if (c->variable) API_TRY(do_update_h(c));          // Variable.f90:1152
+    if (c->variable && (c->p.flags & SPH_FLAG_SINK_CREATION)) {      // Variable.f90:1155, before accretion and bounds
+        int32_t created = 0;
+        API_TRY(sink_creation(c, &created));
+    }
     if (c->p.flags & SPH_FLAG_ACCRETE_CULL) {          // SUMMER_SPH.f90:919-920
         int64_t removed = 0;
         API_TRY(do_accrete(c, &removed));
@@ -456,6 +460,16 @@ int sph_ctx_destroy(sph_ctx *c) {
 }
 
 int64_t sph_count(const sph_ctx *c) { return c ? c->n : -1; }
+int32_t sph_sink_count(const sph_ctx *c) { return c ? c->ns : -1; }
+
+int sph_check_sink_creation(sph_ctx *c, int32_t *created) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    int32_t cr = 0;
+    const int st = sink_creation(c, &cr);
+    if (created) *created = cr;
+    return st;
+}
 
 static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMemcpyKind kind) {
     if (!c) return SPH_ERR_ARG;
@@ -630,6 +644,14 @@ int sph_set_sink_radii(sph_ctx *c, int32_t ns, const double *radius) {
     DeviceGuard g(c->device);
     API_HIP(hipStreamSynchronize(c->stream));
     if (ns > 0) API_HIP(hipMemcpy(c->sink_radius, radius, (size_t)ns * sizeof(double), hipMemcpyHostToDevice));
+    return SPH_OK;
+}
+
+int sph_get_sink_radii(sph_ctx *c, int32_t ns, double *radius) {
+    if (!c || ns < 0 || ns > c->ns || (ns > 0 && !radius)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(hipStreamSynchronize(c->stream));
+    if (ns > 0) API_HIP(hipMemcpy(radius, c->sink_radius, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
     return SPH_OK;
 }
 

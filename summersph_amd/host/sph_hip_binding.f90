@@ -17,6 +17,7 @@ module sph_hip_binding
   public :: sph_set_sink_radii, sph_accrete_and_cull, sph_upload_field, sph_update_h, sph_params_default_variable
   public :: SPH_F_H, SPH_F_OMEGA
   public :: SPH_FLAG_REUSE_DENSITY, SPH_FLAG_VARIABLE_H, SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL
+  public :: SPH_FLAG_SINK_CREATION, sph_sink_count, sph_get_sink_radii
   public :: c_message
 
   integer(c_int), parameter :: SPH_OK = 0
@@ -26,7 +27,7 @@ module sph_hip_binding
 
   integer(c_int), parameter :: SPH_F_H = 17, SPH_F_OMEGA = 18
   integer(c_int32_t), parameter :: SPH_FLAG_REUSE_DENSITY = 1, SPH_FLAG_VARIABLE_H = 2, SPH_FLAG_SELF_GRAVITY = 16
-  integer(c_int32_t), parameter :: SPH_FLAG_ACCRETE_CULL = 32
+  integer(c_int32_t), parameter :: SPH_FLAG_ACCRETE_CULL = 32, SPH_FLAG_SINK_CREATION = 64
 
   type, bind(C) :: sph_params
     real(c_double) :: h, gamma, gamma_m1
@@ -140,6 +141,19 @@ module sph_hip_binding
     integer(c_int64_t) function sph_count(ctx) bind(C, name='sph_count')
       import :: c_int64_t, c_ptr
       type(c_ptr), value :: ctx
+    end function
+
+    ! number of sinks (check_sink_creation of the variable-h variant may add one per step)
+    integer(c_int32_t) function sph_sink_count(ctx) bind(C, name='sph_sink_count')
+      import :: c_int32_t, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function sph_get_sink_radii(ctx, ns, radius) bind(C, name='sph_get_sink_radii')
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: ns
+      real(c_double), intent(out) :: radius(*)
     end function
 
     ! create_tree + get_density + get_pressure_and_sound_speed (:894-897)

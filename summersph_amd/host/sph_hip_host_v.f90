@@ -8,8 +8,8 @@
 !   loop    simulate(bodies, sinks, params)                    (same step sequence, :1085-1165)
 !   saves   make_save: the 10 columns, sinks as x y z vx vy vz 0 m (:921-940)
 ! The device runs the whole loop body: density with Omega, EOS, Barnes-Hut self-gravity, sink gravity, grad-h SPH
-! forces, kicks, drift, dt control, calc_smoothing, sink accretion and the boundary cull.  Not emulated (DESIGN.md):
-! check_sink_creation, max_depth (the octree here has 21 levels), culling of sinks in check_bounds.
+! forces, kicks, drift, dt control, calc_smoothing, check_sink_creation (sinks may be added), sink accretion and the
+! boundary cull.  Not emulated (DESIGN.md): max_depth (the octree here has 21 levels), culling of sinks in check_bounds.
 module sph_hip_host_v
   use, intrinsic :: iso_c_binding
   use sph_hip_binding
@@ -293,13 +293,15 @@ contains
       sinks(i)%mass = s(i, 7)
       sinks(i)%acceleration = s(i, 8:10)
     end do
+    call check(ctx, sph_get_sink_radii(ctx, int(ns, c_int32_t), s(:, 1)), 'sph_get_sink_radii')
+    sinks%radius = s(1:ns, 1)
   end subroutine pull_state
 
   ! The time loop, Variable.f90:1085-1165: per step one sph_step call (density, forces, kick, drift, density,
   ! forces, kick, t += dt, next dt, calc_smoothing, accretion, bounds).  Saves every end_time/1000.
   subroutine simulate(bodies, sinks, params, max_steps, quiet, device, dt_log, sph_only)
     type(particle), allocatable, intent(inout) :: bodies(:)
-    type(sink), intent(inout) :: sinks(:)
+    type(sink), allocatable, intent(inout) :: sinks(:)
     type(param), intent(in) :: params
     integer, intent(in), optional :: max_steps, device
     logical, intent(in), optional :: quiet
@@ -322,7 +324,7 @@ contains
     if (present(device)) dev = device
 
     call check(c_null_ptr, sph_params_default_variable(prm), 'sph_params_default_variable')
-    prm%flags = ior(SPH_FLAG_VARIABLE_H, ior(SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL))
+    prm%flags = ior(ior(SPH_FLAG_VARIABLE_H, SPH_FLAG_SINK_CREATION), ior(SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL))
     if (present(sph_only)) then
       if (sph_only) prm%flags = SPH_FLAG_VARIABLE_H
     end if
@@ -362,6 +364,13 @@ contains
       if (int(sph_count(ctx)) /= size(bodies)) then          ! accretion / cull on the device
         deallocate(bodies)
         allocate(bodies(int(sph_count(ctx))))
+      end if
+      if (int(sph_sink_count(ctx)) /= size(sinks)) then      ! check_sink_creation added a sink
+        deallocate(sinks)
+        allocate(sinks(int(sph_sink_count(ctx))))
+        do i = 1, size(sinks)
+          sinks(i)%spin = 0.0_dp
+        end do
       end if
     end do
 

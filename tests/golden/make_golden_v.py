@@ -40,6 +40,26 @@ def run(mode, infile, *extra):
         return parse_records(outp)
 
 
+def sink_creation_ic():
+    """variable-h disc plus ONE very massive particle well outside it: calc_smoothing drives its h to ~13 (self-dominated),
+    it still passes check_sink_creation's test m (eta/h)^3 > 0.5 ([V]:560) and lies farther than radius + 2h from the
+    file's sink, so a second sink appears at its place in step 1 -- and accretes its own seed in the same step"""
+    rows = ic.keplerian_disc_var(1500, seed=808)
+    k = 24
+    rows[k, 0:3] = [60.0, 0.0, 0.1]
+    rows[k, 3:6] = [0.0, np.sqrt(39.478416442871094 * 1.0 / 60.0), 0.0]
+    rows[k, 7] = 2000.0
+    return rows, k
+
+
+def sink_creation_fixture(td, p):
+    rows, k = sink_creation_ic()
+    f3 = os.path.join(td, "sc.txt"); txtio.write_ic(f3, rows, header=HDR)
+    t = keep_steps(run("traj", f3, *p, 3, "full"), {1, 2, 3})
+    np.savez(os.path.join(HERE, "sinkcv1500_traj.npz"), ic=rows, params=np.array(p), heavy=np.array([k]),
+             **{"full_" + kk: v for kk, v in t.items()})
+
+
 def main():
     if not os.path.exists(DRIVER):
         sys.exit("oracle/_ref/ref_driver_v missing: run oracle/build_ref.sh first (build container only)")
@@ -70,6 +90,7 @@ def main():
         rough[:-1, 9] = np.random.default_rng(9).uniform(1.5, 3.5, 2000)
         f2 = os.path.join(td, "r.txt"); txtio.write_ic(f2, rough, header=HDR)
         np.savez(os.path.join(HERE, "discv2000r_eval.npz"), ic=rough, params=np.array(p), **run("eval", f2, *p))
+        sink_creation_fixture(td, p)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz") and "v" in fn.split("_")[0]:
             print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")

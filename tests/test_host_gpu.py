@@ -100,3 +100,23 @@ def test_fortran_host_variable_h_trajectory(tmp_path, variant):
     for col, f in enumerate("x y z vx vy vz u m alpha h".split()):
         assert rel_err(gas[:, col], g[p + f]) <= 1e-10, f
     assert np.max(np.abs(sinks[:, 0] - g[p + "sx"])) <= 1e-11 and np.max(np.abs(sinks[:, 7] - g[p + "sm"])) <= 1e-14
+
+
+@pytest.mark.gpu
+def test_fortran_host_variable_h_sink_creation(tmp_path):
+    """the variable-h host follows check_sink_creation: a second sink appears (and eats its seed), the snapshot holds
+    two sink rows -- against the real reference's loop"""
+    g = load_golden("sinkcv1500_traj")
+    icf = tmp_path / "ic10.txt"
+    txtio.write_ic(str(icf), g["ic"], header="x y z vx vy vz energy mass alpha smoothing")
+    snap = tmp_path / "final.txt"
+    r = subprocess.run([_build(HOST_BIN_V), str(icf), "-", "3", str(snap)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dts = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("dt ")]
+    assert dts == list(g["full_dt_seq"])
+    gas, sinks = txtio.read_snapshot_v(str(snap))
+    assert gas.shape[0] == 1499 and sinks.shape[0] == 2
+    assert np.max(np.abs(sinks[:, 7] - g["full_s3_sm"]) / g["full_s3_sm"]) <= 1e-14
+    assert np.max(np.abs(sinks[:, 0] - g["full_s3_sx"])) <= 1e-9
+    for col, f in enumerate("x y z vx vy vz u m alpha h".split()):
+        assert rel_err(gas[:, col], g["full_s3_" + f]) <= 1e-9, f

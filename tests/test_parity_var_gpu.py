@@ -109,3 +109,32 @@ def test_full_simulate_trajectory_vs_reference_fixture(capi):
     for f in "x y z vx vy vz u alpha h".split():
         assert rel_err(ctx.field(f), g["full_s5_" + f]) <= 1e-10, f
     ctx.close()
+
+
+def test_sink_creation_vs_reference_fixture(capi):
+    """check_sink_creation ([V]:549-597) inside the loop: a very massive particle outside the disc becomes the seed of a
+    second sink in step 1 (mass 1e-11, radius 2h), which accretes its seed in the same step -- as the real reference does"""
+    g = load_golden("sinkcv1500_traj")
+    ctx, gas, sinks = make_ctx(capi, g, flags=capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL
+                               | capi.FLAG_SINK_CREATION)
+    dts, t, ns = [1e-2], 0.0, [ctx.n]
+    for k in range(1, 4):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt); ns.append(ctx.n)
+        p = f"full_s{k}_"
+        s = ctx.get_sinks()
+        assert s["m"].size == g[p + "sm"].size == 2
+        assert np.max(np.abs(s["m"] - g[p + "sm"]) / g[p + "sm"]) <= 1e-14
+        assert np.max(np.abs(s["radius"] - g[p + "srad"])) <= 1e-10
+        assert np.max(np.abs(s["x"] - g[p + "sx"])) <= 1e-9 and np.max(np.abs(s["vy"] - g[p + "svy"])) <= 1e-9
+        assert ctx.n == g[p + "x"].size
+        for f in "x y z vx vy vz u alpha h".split():
+            assert rel_err(ctx.field(f), g[p + f]) <= 1e-9, (k, f)
+    assert ns == [int(v) for v in g["full_n_seq"]] and ns[1] == 1499
+    assert dts == list(g["full_dt_seq"])
+    ctx.close()
+    # without the flag nothing is created
+    ctx, gas, sinks = make_ctx(capi, g, flags=capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    ctx.step(1e-2, 0.0)
+    assert ctx.get_sinks()["m"].size == 1
+    ctx.close()
