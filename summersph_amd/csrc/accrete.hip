@@ -312,6 +312,34 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     return SPH_OK;
 }
 
+// ---- check_bounds for the sinks, [V]:610-613: sinks outside the box are packed away (variable-h variant only) ----------
+__global__ void sink_cull(int ns, double bound, double *__restrict__ sink, double *__restrict__ srad, int32_t *__restrict__ ns_out) {
+    if (threadIdx.x != 0) return;
+    int o = 0;
+    for (int j = 0; j < ns; j++) {
+        const bool inside = fabs(sink[0 * MAX_SINKS + j]) <= bound && fabs(sink[1 * MAX_SINKS + j]) <= bound &&
+                            fabs(sink[2 * MAX_SINKS + j]) <= bound;
+        if (!inside) continue;
+        if (o != j) {
+            for (int r = 0; r < 10; r++) sink[r * MAX_SINKS + o] = sink[r * MAX_SINKS + j];
+            srad[o] = srad[j];
+        }
+        o++;
+    }
+    *ns_out = o;
+}
+
+int sinks_cull(sph_ctx *c) {
+    if (!c->variable || c->ns == 0) return SPH_OK;
+    sink_cull<<<dim3(1), dim3(64), 0, c->stream>>>(c->ns, c->p.bounding_size, c->sink, c->sink_radius, c->d_flags + 2);
+    AC_CHECK(hipGetLastError());
+    int32_t ns_new = c->ns;
+    AC_CHECK(hipMemcpyAsync(&ns_new, c->d_flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    AC_CHECK(hipStreamSynchronize(c->stream));
+    if (ns_new != c->ns) { c->ns = ns_new; c->rates_valid = false; }
+    return SPH_OK;
+}
+
 // ---- check_sink_creation, [V]:549-597 -------------------------------------------------------------------------------
 // The FIRST particle (caller's order) with m (eta/h)^3 > 0.5 decides: if it lies within radius_j + 2h of an existing
 // sink nothing happens at all (the reference returns), else a sink of mass 1e-11 and radius 2h is created at its

@@ -268,7 +268,8 @@ int do_update_h(sph_ctx *c) {
 int do_accrete(sph_ctx *c, int64_t *removed) {
     if (!c->order_valid) { c->err = "sph_accrete_and_cull: needs the grid of the current positions (call sph_density first)"; return SPH_ERR_STATE; }
     if (c->n_owned != c->n) { c->err = "sph_accrete_and_cull: not available with ghost particles"; return SPH_ERR_STATE; }
-    return accrete_and_cull(c, removed);
+    API_TRY(accrete_and_cull(c, removed));
+    return sinks_cull(c);                               // Variable.f90:610-613 (after the accretion, like the gas cull)
 }
 
 int one_step_device_dt(sph_ctx *c) {

@@ -9,7 +9,7 @@
 !   saves   make_save: the 10 columns, sinks as x y z vx vy vz 0 m (:921-940)
 ! The device runs the whole loop body: density with Omega, EOS, Barnes-Hut self-gravity, sink gravity, grad-h SPH
 ! forces, kicks, drift, dt control, calc_smoothing, check_sink_creation (sinks may be added), sink accretion and the
-! boundary cull.  Not emulated (DESIGN.md): max_depth (the octree here has 21 levels), culling of sinks in check_bounds.
+! boundary cull of gas and sinks.  Not emulated (DESIGN.md): max_depth (the octree here has 21 levels).
 module sph_hip_host_v
   use, intrinsic :: iso_c_binding
   use sph_hip_binding

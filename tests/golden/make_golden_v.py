@@ -60,6 +60,16 @@ def sink_creation_fixture(td, p):
              **{"full_" + kk: v for kk, v in t.items()})
 
 
+def sink_cull_fixture(td, p):
+    """[V]'s check_bounds also packs the SINKS: a second sink starts outside the box and is gone after step 1"""
+    rows = ic.keplerian_disc_var(1000, seed=909)
+    far = np.zeros((1, 10)); far[0, 0:3] = [1600.0, 2.0, 0.0]; far[0, 7] = 0.5
+    rows = np.vstack([rows[:300], far, rows[300:]])
+    f4 = os.path.join(td, "cull.txt"); txtio.write_ic(f4, rows, header=HDR)
+    t = keep_steps(run("traj", f4, *p, 3, "full"), {1, 3})
+    np.savez(os.path.join(HERE, "sinkcullv1000_traj.npz"), ic=rows, params=np.array(p), **{"full_" + kk: v for kk, v in t.items()})
+
+
 def main():
     if not os.path.exists(DRIVER):
         sys.exit("oracle/_ref/ref_driver_v missing: run oracle/build_ref.sh first (build container only)")
@@ -91,6 +101,7 @@ def main():
         f2 = os.path.join(td, "r.txt"); txtio.write_ic(f2, rough, header=HDR)
         np.savez(os.path.join(HERE, "discv2000r_eval.npz"), ic=rough, params=np.array(p), **run("eval", f2, *p))
         sink_creation_fixture(td, p)
+        sink_cull_fixture(td, p)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz") and "v" in fn.split("_")[0]:
             print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")

@@ -138,3 +138,25 @@ def test_sink_creation_vs_reference_fixture(capi):
     ctx.step(1e-2, 0.0)
     assert ctx.get_sinks()["m"].size == 1
     ctx.close()
+
+
+def test_sinks_outside_the_box_are_culled(capi):
+    """[V]'s check_bounds packs the sinks too ([V]:610-613): the far sink of the file pulls on the gas during step 1 and
+    is gone afterwards -- 3 steps against the real reference"""
+    g = load_golden("sinkcullv1000_traj")
+    ctx, gas, sinks = make_ctx(capi, g, flags=capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL
+                               | capi.FLAG_SINK_CREATION)
+    assert ctx.get_sinks()["m"].size == 2
+    dts, t = [1e-2], 0.0
+    for k in range(1, 4):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt)
+        if k in (1, 3):
+            p = f"full_s{k}_"
+            s = ctx.get_sinks()
+            assert s["m"].size == 1 and s["m"][0] == g[p + "sm"][0]
+            assert abs(s["x"][0] - g[p + "sx"][0]) <= 1e-12
+            for f in "x y z vx vy vz u alpha h".split():
+                assert rel_err(ctx.field(f), g[p + f]) <= 1e-10, (k, f)
+    assert dts == list(g["full_dt_seq"])
+    ctx.close()
