@@ -338,7 +338,7 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
                                                      double hfix, double soft2, double theta, double G,
                                                      const double *__restrict__ gt, int nq, double dq, double *__restrict__ ax,
                                                      double *__restrict__ ay, double *__restrict__ az, const int32_t *__restrict__ orig,
-                                                     int32_t n_owned, unsigned long long *__restrict__ stats) {
+                                                     int32_t n_owned, unsigned long long *__restrict__ stats, double rb_size) {
     // nt targets (the context's cell-sorted slots); the tree has n leaves: the same particles (leaf_of: slot -> leaf),
     // or an external source set (multi-GPU: every GPU's particles; leaf_of == nullptr).  A target's own leaf needs no
     // special case then: its direction is exactly 0 and it adds 0 * f.
@@ -381,6 +381,12 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
             sums++;
         }
         visits++;
+        if (stats && (threadIdx.x & 63) == 0) {          // debug histogram: visits by node size (levels below the root)
+            const double ratio = r.size2 > 0.0 ? r.size2 / (rb_size * rb_size) : 0.0;
+            int lv = 0;
+            while (lv < 15 && ratio > 0.0 && ratio < 1.0 / (double)(1ull << (2 * lv))) lv++;
+            atomicAdd(&stats[2 + (r.size2 > 0.0 ? lv : 15)], 1ull);
+        }
         if (open_any) {
             if (active && accept) { active = false; resume = r.next_skip; }   // done with this subtree
             node = r.next_open;
@@ -544,18 +550,21 @@ hipError_t launch_gravity(sph_ctx *c) {
         TreeArrays ta = tree_arrays(c);
         unsigned long long *stats = nullptr;
         if (wave_walk == 2) {                                           // debug: visit / contribution counts
-            if (hipMalloc(reinterpret_cast<void **>(&stats), 16) != hipSuccess) return hipGetLastError();
-            (void)hipMemsetAsync(stats, 0, 16, c->stream);
+            if (hipMalloc(reinterpret_cast<void **>(&stats), 18 * 8) != hipSuccess) return hipGetLastError();
+            (void)hipMemsetAsync(stats, 0, 18 * 8, c->stream);
         }
         grav_walk_wave<<<dim3((unsigned)((nt + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
             (int)nt, (int)n, reinterpret_cast<const WalkRec *>(c->g_wrec), ta.leafA, reinterpret_cast<const double4 *>(c->drec),
             ext ? nullptr : c->g_leaf_of, c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
             c->p.theta, c->p.G, c->grav_tab, c->p.nq, 2.0 / c->p.nq, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
-            (int32_t)c->n_owned, stats);
+            (int32_t)c->n_owned, stats, rb.size);
         if (stats) {
-            unsigned long long h[2] = {0, 0};
+            unsigned long long h[18] = {0};
             (void)hipStreamSynchronize(c->stream);
-            (void)hipMemcpy(h, stats, 16, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h, stats, 18 * 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[grav_walk_wave] visits per wave by level (0..14, leaves):");
+            for (int k = 0; k < 16; k++) fprintf(stderr, " %.1f", (double)h[2 + k] / (double)((nt + 63) / 64));
+            fprintf(stderr, "\n");
             (void)hipFree(stats);
             fprintf(stderr, "[grav_walk_wave] n=%lld wave visits/wave=%.1f contributions/particle=%.1f\n", (long long)n,
                     (double)h[0] / (double)((n + 63) / 64), (double)h[1] / (double)n);

@@ -259,9 +259,12 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                 const double g21 = g2 + axis_gap2(p[s1], g.org[s1] + c1 * e, e);
                 if (g21 > rg2) continue;
                 const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
-                if (cell_start[row + c0hi + 1] <= cb || cell_start[row + c0lo] >= ce) continue;   // row not in this chunk
+                int js = cell_start[row + c0lo];
+                if (cell_start[row + c0hi + 1] <= cb || js >= ce) continue;                       // row not in this chunk
                 for (int c0 = c0lo; c0 <= c0hi; c0++) {
-                    const int jb = max(cell_start[row + c0], cb), je = min(cell_start[row + c0 + 1], ce);
+                    const int jn = cell_start[row + c0 + 1];             // one table read per cell: the end is the next start
+                    const int jb = max(js, cb), je = min(jn, ce);
+                    js = jn;
                     if (jb >= je) continue;
                     const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
                     const double rc = 2.0 * fmax(him, cell_hmax[row + c0]);
