@@ -247,12 +247,12 @@ def main():
         flops = (FLOPS_DENSITY_PAIR + FLOPS_FORCE_PAIR) * 2 * st.nlist_mean * args.n * args.steps / elapsed / 1e12
         # HBM traffic of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 on
         # itself); only quoted when it was measured on this very workload
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "r01_forces_traffic.json")
-        if os.path.exists(tf) and world == 1 and not variable:
+        if os.path.exists(tf) and world == 1 and not variable and args.ic == "disc":
             rec = json.load(open(tf))
             if rec.get("workload_particles") == args.n:
-                traffic = rec["traffic_bytes_per_launch"]
+                traffic, traffic_src = rec["traffic_bytes_per_launch"], rec.get("source")
         wl = ((f"thin Keplerian ring (r ~ N(r0, 0.05 r0)), " if args.ic == "ring" and not variable else "uniform Keplerian disc, ")
               + f"{args.n} gas particles + 1 sink per GPU, "
               + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
@@ -271,7 +271,7 @@ def main():
                                       f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed {args.backend})",
                        "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
             "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else "forces_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
                          "note": "compulsory HBM traffic is tiny for this path; the pair loop is bound by the L1/TA gather "
                                  "path and fp64 VALU (profiles/), see valu_fp64"},
