@@ -266,6 +266,7 @@ class DistSim:
                              "a single GPU runs it inside sph_step / sph_run")
         self.stats_removed = 0
         self.counts_all = None    # owned particles of every rank (changes with migrations only)
+        self.sources_valid = False  # the all-gathered {x, y, z, m} of all particles match the current positions and owners
         self.boxes = None         # every rank's owned bounding box at the last ghost exchange (host)
         self._pred, self._pred_event, self._pred_pinned = None, None, None
         self.pred_for_drift = False   # the boxes predicted at the last reduction describe the positions after the drift just done
@@ -523,12 +524,14 @@ class DistSim:
                     be.upload(self.owned)
                 self.in_backend = True
                 self.counts_all = None
+                self.sources_valid = False
             if self.P > 1:
                 with self._phase("ghost_exchange"):
                     self._exchange_ghosts()
-                if self.gravity or self.variable:
+                if (self.gravity or self.variable) and not self.sources_valid:
                     with self._phase("gravity_sources"):
                         self._gravity_sources()
+                    self.sources_valid = True
             with self._phase("compute"):
                 be.density()
             pending, tag = (self._refresh_ghost_start(["rho", "omega"] if self.variable else ["rho"]) if self.P > 1 else None), "ghost_rho"
@@ -570,6 +573,7 @@ class DistSim:
             be.kick()
             be.drift()
         self.pos_dirty = True
+        self.sources_valid = False
         self.pred_for_drift = True       # the reduction of the evaluation above predicted where this drift takes everybody
         self.since_migrate += 1
         self.evaluate()
@@ -599,6 +603,7 @@ class DistSim:
         self.n_owned = int(self.gid.numel())
         self.stats_removed += removed
         self.counts_all = None
+        self.sources_valid = False
         self.pos_dirty = True          # the ghosts were dropped with the accreted particles: exchange before the next pass
         self.vel_dirty = False
 
