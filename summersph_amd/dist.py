@@ -223,7 +223,7 @@ class DistSim:
     arrays, STATE keys, optional 'gid'); `bounds` are the interior slab edges shared by all ranks."""
 
     def __init__(self, backend, gas: dict, sinks: dict, bounds: np.ndarray, h: float | None = None,
-                 group=None, comm_device=None, migrate: bool = True, migrate_every: int = 8):
+                 group=None, comm_device=None, migrate: bool = True, migrate_every: int = 32):
         self.be = backend
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
