@@ -77,7 +77,8 @@ typedef struct sph_params {
                                    kernel normalised with h_i and REAL(4) pi, nq = 2500, Omega,
                                    h update after every step.  Upload h with sph_upload_field. */
 #define SPH_FLAG_SELF_GRAVITY 16 /* find_forces WITH the Barnes-Hut gas self-gravity term (particle_gravforces,
-                                   [F]:249-290, 825): sph_forces then equals find_forces as it is.  Single GPU. */
+                                   [F]:249-290, 825): sph_forces then equals find_forces as it is (several GPUs:
+                                   sph_set_gravity_sources_dev) */
 #define SPH_FLAG_ACCRETE_CULL 32 /* sph_step / sph_run also do the end-of-step sink accretion and boundary cull
                                    of simulate() ([F]:919-920): the particle count may shrink (sph_count) */
 #define SPH_FLAG_SINK_CREATION 64 /* variable h: sph_step / sph_run also run check_sink_creation ([V]:549-597, 1155): the
