@@ -477,7 +477,7 @@ int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, i
     AC_CHECK(launch_iota(c, c->inv, n_new));
     AC_CHECK(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
-    return SPH_OK;
+    return sinks_cull(c);                              // [V]:610-613; the sinks are replicated: every rank drops the same ones
 }
 
 }  // namespace sph

@@ -139,8 +139,9 @@ def _worker_var(rank, world, port, nsteps, outdir, ic_rows, params, full):
     for _ in range(nsteps):
         dts.append(sim.step(dts[-1]))
     st = sim.gather_state()
+    s = sim.be.get_sinks()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), dts=np.array(dts), ghosts=sim.stats["ghosts"],
-             h=sim.owned[9].cpu().numpy(), **st)
+             h=sim.owned[9].cpu().numpy(), sm=s["m"], sx=s["x"], **st)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -202,3 +203,16 @@ def test_hip_ghost_path_at_scale_vs_single_context(tmp_path):
         assert rel_err(merged, ctx.field(f)) <= 1e-12, f
     assert abs(parts[0]["sx"][0] - ctx.get_sinks()["x"][0]) <= 1e-13
     ctx.close()
+
+
+def test_hip_variable_h_sink_cull_across_ranks(tmp_path):
+    """[V]'s check_bounds drops the sink that starts outside the box -- on every rank alike (the sinks are replicated)"""
+    g = load_golden("sinkcullv1000_traj")
+    mp.spawn(_worker_var, args=(2, _free_port(), 3, str(tmp_path), g["ic"], g["params"], True), nprocs=2, join=True)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert p["sm"].size == 1 and p["sm"][0] == g["full_s3_sm"][0] and abs(p["sx"][0] - g["full_s3_sx"][0]) <= 1e-12
+    for f in FIELDS + ["h"]:
+        assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-10, f
