@@ -163,6 +163,12 @@ int32_t sph_sink_count(const sph_ctx *ctx);
  * particle (caller's order) with m (eta/h)^3 > 0.5 either lies within radius + 2h of a sink (nothing happens) or a
  * sink of mass 1e-11 and radius 2h is created at its position; *created = 0/1 */
 int sph_check_sink_creation(sph_ctx *ctx, int32_t *created);
+/* the two halves of it for several GPUs: the first candidate among the owned particles as a record of SPH_SINK_CAND
+ * doubles {particle number or +inf, x, y, z, vx, vy, vz, h, 0} in device memory; the caller all-gathers the records,
+ * picks the lowest number and hands that record to every context, which applies the distance test and the creation */
+#define SPH_SINK_CAND 9
+int sph_sink_candidate_dev(sph_ctx *ctx, double *d_cand);
+int sph_add_sink_checked_dev(sph_ctx *ctx, const double *d_cand, int32_t *created);
 /* one field in the caller's particle order, host or device source (e.g. SPH_F_H after sph_upload) */
 int sph_upload_field(sph_ctx *ctx, int field, const double *host, int64_t n);
 int sph_upload_field_dev(sph_ctx *ctx, int field, const double *d_vals, int64_t n);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "sph_set_sink_radii", "sph_accrete_and_cull",
     "sph_params_default", "sph_params_default_variable", "sph_upload_field", "sph_upload_field_dev", "sph_update_h",
     "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version",
-    "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count", "sph_sink_count", "sph_check_sink_creation", "sph_get_sink_radii",
+    "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count", "sph_sink_count", "sph_check_sink_creation", "sph_get_sink_radii", "sph_sink_candidate_dev", "sph_add_sink_checked_dev",
     "sph_density", "sph_forces", "sph_kick", "sph_drift", "sph_next_dt", "sph_step", "sph_run",
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
@@ -93,6 +93,8 @@ def load():
     lib.sph_sink_count.argtypes = [C.c_void_p]
     lib.sph_check_sink_creation.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.sph_get_sink_radii.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.sph_sink_candidate_dev.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sph_add_sink_checked_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.sph_stream.restype = C.c_void_p
     lib.sph_stream.argtypes = [C.c_void_p]
     lib.sph_ctx_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
@@ -243,6 +245,14 @@ class Context:
         out["radius"] = np.zeros(ns)
         self._ck(self.lib.sph_get_sink_radii(self._h, ns, _hp(out["radius"])))
         return out
+
+    def sink_candidate_dev(self, dev_ptr: int):
+        self._ck(self.lib.sph_sink_candidate_dev(self._h, C.c_void_p(int(dev_ptr))))
+
+    def add_sink_checked_dev(self, dev_ptr: int) -> bool:
+        cr = C.c_int32(0)
+        self._ck(self.lib.sph_add_sink_checked_dev(self._h, C.c_void_p(int(dev_ptr)), C.byref(cr)))
+        return bool(cr.value)
 
     def check_sink_creation(self) -> bool:
         cr = C.c_int32(0)

@@ -345,55 +345,84 @@ int sinks_cull(sph_ctx *c) {
 // sink nothing happens at all (the reference returns), else a sink of mass 1e-11 and radius 2h is created at its
 // position with its velocity (the particle stays).  At most one sink per call.
 __global__ __launch_bounds__(AB) void sink_create_scan(const double4 *__restrict__ drec, const double *__restrict__ h,
-                                                       const int32_t *__restrict__ orig, int64_t n, int32_t n_owned, double eta,
-                                                       int32_t *__restrict__ first_id) {
+                                                       const int32_t *__restrict__ orig, const int32_t *__restrict__ number,
+                                                       int64_t n, int32_t n_owned, double eta, int32_t *__restrict__ first_no) {
     const int64_t i = (int64_t)blockIdx.x * AB + threadIdx.x;
     if (i >= n || orig[i] >= n_owned) return;
     const double t = eta / h[i];
-    if (drec[i].w * (t * t * t) > 0.5) atomicMin(first_id, orig[i]);          // [V]:560
+    if (drec[i].w * (t * t * t) > 0.5) atomicMin(first_no, number ? number[orig[i]] : orig[i]);          // [V]:560
 }
 
-__global__ void sink_create_apply(const int32_t *__restrict__ first_id, const int32_t *__restrict__ inv,
-                                  const double4 *__restrict__ drec, const double *__restrict__ h, const double *__restrict__ vx,
-                                  const double *__restrict__ vy, const double *__restrict__ vz, int ns, double *__restrict__ sink,
-                                  double *__restrict__ srad, int32_t *__restrict__ created) {
+// candidate record: {particle number (+inf: none), x, y, z, vx, vy, vz, h, 0}
+__global__ __launch_bounds__(AB) void sink_create_fetch(const double4 *__restrict__ drec, const double *__restrict__ h,
+                                                        const double *__restrict__ vx, const double *__restrict__ vy,
+                                                        const double *__restrict__ vz, const int32_t *__restrict__ orig,
+                                                        const int32_t *__restrict__ number, int64_t n, int32_t n_owned,
+                                                        const int32_t *__restrict__ first_no, double *__restrict__ cand) {
+    const int64_t i = (int64_t)blockIdx.x * AB + threadIdx.x;
+    const int32_t want = *first_no;
+    if (i == 0 && want == 0x7fffffff) { cand[0] = INFINITY; for (int k = 1; k < 9; k++) cand[k] = 0.0; }
+    if (i >= n || orig[i] >= n_owned || want == 0x7fffffff) return;
+    if ((number ? number[orig[i]] : orig[i]) != want) return;
+    const double4 p = drec[i];
+    cand[0] = (double)want; cand[1] = p.x; cand[2] = p.y; cand[3] = p.z;
+    cand[4] = vx[i]; cand[5] = vy[i]; cand[6] = vz[i]; cand[7] = h[i]; cand[8] = 0.0;
+}
+
+__global__ void sink_create_apply(const double *__restrict__ cand, int ns, double *__restrict__ sink, double *__restrict__ srad,
+                                  int32_t *__restrict__ created) {
     if (threadIdx.x != 0) return;
     *created = 0;
-    const int32_t id = *first_id;
-    if (id == 0x7fffffff || ns >= MAX_SINKS) return;
-    const int32_t s = inv[id];
-    const double4 p = drec[s];
-    const double hi = h[s];
+    if (!(cand[0] < 1.0e300) || ns >= MAX_SINKS) return;
+    const double px = cand[1], py = cand[2], pz = cand[3], hi = cand[7];
     for (int j = 0; j < ns; j++) {
-        const double d0 = sink[0 * MAX_SINKS + j] - p.x, d1 = sink[1 * MAX_SINKS + j] - p.y, d2 = sink[2 * MAX_SINKS + j] - p.z;
+        const double d0 = sink[0 * MAX_SINKS + j] - px, d1 = sink[1 * MAX_SINKS + j] - py, d2 = sink[2 * MAX_SINKS + j] - pz;
         const double dr = sqrt(d0 * d0 + d1 * d1 + d2 * d2);                      // [V]:562
         if (dr < srad[j] + 2 * hi) return;                                        // [V]:563-565
     }
-    sink[0 * MAX_SINKS + ns] = p.x; sink[1 * MAX_SINKS + ns] = p.y; sink[2 * MAX_SINKS + ns] = p.z;
-    sink[3 * MAX_SINKS + ns] = vx[s]; sink[4 * MAX_SINKS + ns] = vy[s]; sink[5 * MAX_SINKS + ns] = vz[s];
+    sink[0 * MAX_SINKS + ns] = px; sink[1 * MAX_SINKS + ns] = py; sink[2 * MAX_SINKS + ns] = pz;
+    sink[3 * MAX_SINKS + ns] = cand[4]; sink[4 * MAX_SINKS + ns] = cand[5]; sink[5 * MAX_SINKS + ns] = cand[6];
     sink[6 * MAX_SINKS + ns] = 0.00000000001;                                     // [V]:581
     sink[7 * MAX_SINKS + ns] = 0.0; sink[8 * MAX_SINKS + ns] = 0.0; sink[9 * MAX_SINKS + ns] = 0.0;
     srad[ns] = 2 * hi;                                                            // [V]:582
     *created = 1;
 }
 
-int sink_creation(sph_ctx *c, int32_t *created) {
-    *created = 0;
-    if (!c->variable || c->n == 0) return SPH_OK;
-    if (!c->order_valid) { c->err = "sink creation: needs the sorted order of the current positions"; return SPH_ERR_STATE; }
+// the first candidate among this context's owned particles -> d_cand (9 doubles, device)
+int sink_candidate(sph_ctx *c, double *d_cand) {
+    if (!c->variable) { c->err = "sink creation: variable-h contexts only"; return SPH_ERR_STATE; }
+    if (c->n > 0 && !c->order_valid) { c->err = "sink creation: needs the sorted order of the current positions"; return SPH_ERR_STATE; }
     const int32_t big = 0x7fffffff;
     AC_CHECK(hipMemcpyAsync(c->d_flags + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    sink_create_scan<<<dim3((unsigned)((c->n + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(
-        reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_H], c->orig, c->n, (int32_t)c->n_owned, c->p.eta, c->d_flags + 3);
-    sink_create_apply<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_flags + 3, c->inv, reinterpret_cast<const double4 *>(c->drec),
-                                                           c->f[SPH_F_H], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->ns, c->sink,
-                                                           c->sink_radius, c->d_flags + 2);
+    const unsigned gb = (unsigned)((std::max<int64_t>(c->n, 1) + AB - 1) / AB);
+    const int32_t *num = c->numbers_set ? c->number : nullptr;
+    sink_create_scan<<<dim3(gb), dim3(AB), 0, c->stream>>>(reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_H], c->orig, num, c->n,
+                                                           (int32_t)c->n_owned, c->p.eta, c->d_flags + 3);
+    sink_create_fetch<<<dim3(gb), dim3(AB), 0, c->stream>>>(reinterpret_cast<const double4 *>(c->drec), c->f[SPH_F_H], c->f[SPH_F_VX],
+                                                            c->f[SPH_F_VY], c->f[SPH_F_VZ], c->orig, num, c->n, (int32_t)c->n_owned,
+                                                            c->d_flags + 3, d_cand);
+    AC_CHECK(hipGetLastError());
+    return SPH_OK;
+}
+
+// distance test against the existing sinks, then the new sink ([V]:561-595); d_cand: the winning candidate record
+int sink_add_checked(sph_ctx *c, const double *d_cand, int32_t *created) {
+    *created = 0;
+    sink_create_apply<<<dim3(1), dim3(64), 0, c->stream>>>(d_cand, c->ns, c->sink, c->sink_radius, c->d_flags + 2);
     AC_CHECK(hipGetLastError());
     int32_t flag = 0;
     AC_CHECK(hipMemcpyAsync(&flag, c->d_flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     AC_CHECK(hipStreamSynchronize(c->stream));
     if (flag) { c->ns += 1; *created = 1; c->rates_valid = false; }
     return SPH_OK;
+}
+
+int sink_creation(sph_ctx *c, int32_t *created) {
+    *created = 0;
+    if (!c->variable || c->n == 0) return SPH_OK;
+    double *cand = c->bbox_part + 1024 * 6 + 16;       // spare doubles behind the bbox partials and results
+    { const int st = sink_candidate(c, cand); if (st != SPH_OK) return st; }
+    return sink_add_checked(c, cand, created);
 }
 
 // ---- multi-GPU: mark + per-rank sums, then (after the caller all-gathered the sums) sink update + compaction ----------

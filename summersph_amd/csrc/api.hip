@@ -409,7 +409,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 640 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
     std::memset(c->h_pinned, 0, 640 * sizeof(double));
-    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 16, "bbox")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 32, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
@@ -860,6 +860,21 @@ int sph_set_numbers_dev(sph_ctx *c, int64_t first, int64_t count, const int64_t 
     c->numbers_set = true;
     if (c->variable) { c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; }
     return SPH_OK;
+}
+
+int sph_sink_candidate_dev(sph_ctx *c, double *d_cand) {
+    if (!c || !d_cand) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    return sink_candidate(c, d_cand);
+}
+
+int sph_add_sink_checked_dev(sph_ctx *c, const double *d_cand, int32_t *created) {
+    if (!c || !d_cand) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    int32_t cr = 0;
+    const int st = sink_add_checked(c, d_cand, &cr);
+    if (created) *created = cr;
+    return st;
 }
 
 int sph_set_dt(sph_ctx *c, double dt, double t) {

@@ -226,6 +226,8 @@ hipError_t launch_gravity(sph_ctx *c);
 // accretion + boundary cull (accrete.hip)
 int accrete_and_cull(sph_ctx *c, int64_t *removed);
 int sink_creation(sph_ctx *c, int32_t *created);
+int sink_candidate(sph_ctx *c, double *d_cand);    // multi-GPU halves of sink_creation
+int sink_add_checked(sph_ctx *c, const double *d_cand, int32_t *created);
 int sinks_cull(sph_ctx *c);                         // [V] check_bounds for the sinks    // [V] check_sink_creation; may add one sink (c->ns grows)
 int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials);       // multi-GPU: marks + per-rank sink sums
 int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, int32_t *d_keep_out, int64_t *removed);

@@ -162,6 +162,19 @@ class HipBackend:
     def accrete(self) -> bool:
         return bool(self.ctx.params.flags & self.capi.FLAG_ACCRETE_CULL)
 
+    @property
+    def sink_creation(self) -> bool:
+        return bool(self.ctx.params.flags & self.capi.FLAG_SINK_CREATION)
+
+    def sink_candidate(self) -> torch.Tensor:
+        out = torch.empty(9, dtype=torch.float64, device=self.device)
+        self.ctx.sink_candidate_dev(out.data_ptr())
+        return out
+
+    def add_sink_checked(self, cand: torch.Tensor) -> bool:
+        cand = cand.contiguous()
+        return self.ctx.add_sink_checked_dev(cand.data_ptr())
+
     def accrete_mark(self, src_offset: int) -> torch.Tensor:
         out = torch.empty(ACC_PARTIALS, dtype=torch.float64, device=self.device)
         self.ctx.accrete_mark_dev(src_offset, out.data_ptr())
@@ -265,6 +278,8 @@ class DistSim:
             raise ValueError("accretion through DistSim needs several ranks and SPH_FLAG_SELF_GRAVITY (the shared octree); "
                              "a single GPU runs it inside sph_step / sph_run")
         self.stats_removed = 0
+        # check_sink_creation ([V]:549-597): the first particle by global number that qualifies, found with one all-gather
+        self.sink_creation = bool(getattr(backend, "sink_creation", False)) and self.variable
         self.counts_all = None    # owned particles of every rank (changes with migrations only)
         self.sources_valid = False  # the all-gathered {x, y, z, m} of all particles match the current positions and owners
         self.boxes = None         # every rank's owned bounding box at the last ghost exchange (host)
@@ -587,6 +602,10 @@ class DistSim:
                 be.update_h()                # calc_smoothing, [V]:1152; the ghosts' h is stale now: full exchange next
             self.pos_dirty = True
             self.vel_dirty = False
+        if self.sink_creation and self.P > 1:
+            with self._phase("accrete"):
+                cands = self._all_gather(be.sink_candidate()).to(self.dev)         # [P, 9]; row 0 = particle number or +inf
+                be.add_sink_checked(cands[torch.argmin(cands[:, 0])])
         if self.accrete and self.P > 1:
             with self._phase("accrete"):
                 self._accrete_and_cull()

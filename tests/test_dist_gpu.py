@@ -133,7 +133,7 @@ def _worker_var(rank, world, port, nsteps, outdir, ic_rows, params, full):
     gamma, eta, tol, maxlen, scale = (float(v) for v in params)
     kw = dict(variable=True, gamma=gamma, gamma_m1=gamma - 1.0, eta=eta, h_tol=tol, h_max_length=maxlen, dt_scale=scale)
     if full:
-        kw["flags"] = capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL
+        kw["flags"] = capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL | capi.FLAG_SINK_CREATION
     sim = DistSim(HipBackend(0, **kw), mine, sinks, bounds, comm_device="cpu", migrate_every=2)
     dts = [1e-2]
     for _ in range(nsteps):
@@ -216,3 +216,20 @@ def test_hip_variable_h_sink_cull_across_ranks(tmp_path):
         assert p["sm"].size == 1 and p["sm"][0] == g["full_s3_sm"][0] and abs(p["sx"][0] - g["full_s3_sx"][0]) <= 1e-12
     for f in FIELDS + ["h"]:
         assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-10, f
+
+
+def test_hip_variable_h_sink_creation_across_ranks(tmp_path):
+    """check_sink_creation on 2 ranks: the candidate with the lowest global number wins (one all-gather), every rank adds
+    the same sink, which then accretes its seed through the shared-octree accretion"""
+    g = load_golden("sinkcv1500_traj")
+    mp.spawn(_worker_var, args=(2, _free_port(), 3, str(tmp_path), g["ic"], g["params"], True), nprocs=2, join=True)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    gid = np.concatenate([p["gid"] for p in parts])
+    order = np.argsort(gid)
+    assert gid.size == 1499
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert p["sm"].size == 2 and np.max(np.abs(p["sm"] - g["full_s3_sm"]) / g["full_s3_sm"]) <= 1e-14
+        assert np.max(np.abs(p["sx"] - g["full_s3_sx"])) <= 1e-9
+    for f in FIELDS + ["h"]:
+        assert rel_err(np.concatenate([p[f] for p in parts])[order], g["full_s3_" + f]) <= 1e-9, f
