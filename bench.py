@@ -115,7 +115,7 @@ def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags, ring=Fals
     rows = ic.keplerian_disc_var(n, seed=303) if variable else (
         ic.thin_ring(n, seed=404) if ring else ic.keplerian_disc(n, seed=202, nngb=nngb))
     gas, sinks = ic.split_rows(rows)
-    ctx = capi.Context(device=device, variable=True) if variable else capi.Context(device=device, flags=flags)
+    ctx = capi.Context(device=device, variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable else capi.Context(device=device, flags=flags)
     dev = [torch.from_numpy(gas[k]).to(f"cuda:{device}") for k in "x y z vx vy vz u m alpha".split()]
     torch.cuda.synchronize()
     ctx.upload_dev(n, [t.data_ptr() for t in dev])               # inputs resident in HBM
@@ -189,7 +189,8 @@ def main():
     variable = args.mode == "variable"
     flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
         | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0) \
-        | (capi.FLAG_ACCRETE_CULL if args.full_simulate else 0)
+        | (capi.FLAG_ACCRETE_CULL if args.full_simulate else 0) \
+        | (capi.FLAG_SINK_CREATION if args.full_simulate and args.mode == "variable" else 0)
 
     # ---- headline workload -----------------------------------------------------------------------
     sim = None
