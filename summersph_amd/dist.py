@@ -288,7 +288,7 @@ class DistSim:
         self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
         self.phase_s = {}
         self._gather_into = True  # all_gather_into_tensor until the backend refuses it
-        if self.P > 1 and self.migrate:
+        if self.P > 1:
             self.prime()
 
     @contextlib.contextmanager
@@ -342,6 +342,13 @@ class DistSim:
         pay = torch.cat([x[None, :].repeat(9, 1), torch.arange(16, device=self.dev).to(torch.float64)[None, :]])
         part = torch.cat([pay[:, dest == 0], pay[:, dest == 1]], dim=1)
         part[:9].contiguous(); part[9].to(torch.int64)
+        # ... and the first collective / point-to-point message between two ranks sets up their connection: one of each
+        # with the slab neighbours now
+        self._all_gather(torch.zeros(PARTIALS, dtype=torch.float64, device=self.dev))
+        self._all_gather(torch.zeros(self.P, dtype=torch.int64))
+        one = torch.zeros((1, 8), dtype=torch.float64, device=self.dev)
+        send = [one if abs(q - self.rank) == 1 else None for q in range(self.P)]
+        self._p2p(send, [8 if abs(q - self.rank) == 1 else 0 for q in range(self.P)], 1)
 
     def _all_gather(self, row: torch.Tensor) -> torch.Tensor:
         """every rank contributes one 1-D tensor of equal length -> [P, len] on the communication device"""
