@@ -307,7 +307,8 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(launch_iota(c, c->orig, n_new));
     AC_CHECK(launch_iota(c, c->inv, n_new));
     AC_CHECK(hipStreamSynchronize(c->stream));
-    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = false;
+    c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
+    c->h_refresh_ok = false;
     *removed = n - n_new;
     return SPH_OK;
 }

@@ -42,7 +42,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->drec); ctx_free(c, c->frec);
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
-    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class);
+    ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class); ctx_free(c, c->leaf_half);
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
@@ -83,6 +83,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
         API_TRY(ctx_alloc(c, &c->h_new, (size_t)cap, "h scratch"));
         API_TRY(ctx_alloc(c, &c->ntail, (size_t)cap, "margin counts"));
+        API_TRY(ctx_alloc(c, &c->leaf_half, (size_t)cap, "leaf half edges"));
     }
     {   // octree path keys: leaf boxes (variable h), self-gravity tree, accretion
         API_TRY(ctx_alloc(c, &c->mkeys, (size_t)cap, "octree keys"));
@@ -162,6 +163,17 @@ void resolve_timing(sph_ctx *c) {
 }
 
 int do_density(sph_ctx *c) {
+    static const bool no_refresh = getenv("SPH_NO_H_REFRESH") != nullptr;      // A/B switch
+    if (!no_refresh && !c->grid_valid && c->variable && c->h_refresh_ok && c->order_valid && c->leaf_valid && c->n_slots == c->n) {
+        // same positions, same particles, new h (calc_smoothing, Variable.f90:1152): the sorted order, the cell table and
+        // the leaf cells stand; only what depends on h is redone -- and a self-gravity tree stays valid
+        API_TRY(varh_h_stats(c));
+        { Timed t(c, SPH_K_LEAF); API_TRY(varh_refresh_h(c)); }
+        { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
+        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
+        c->grid_valid = true;
+    }
+    c->h_refresh_ok = false;
     if (!c->grid_valid) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
@@ -169,7 +181,9 @@ int do_density(sph_ctx *c) {
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         c->wave_class_valid = false; c->interior_done = false;
         if (c->variable) {
+            c->leaf_valid = false;
             { Timed t(c, SPH_K_LEAF); API_TRY(varh_leaf_build(c)); }
+            c->leaf_valid = true;
             { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
         } else {
             Timed t(c, SPH_K_NLIST); API_TRY(c->tiled ? nlist_build_tiled(c) : nlist_build(c));
@@ -260,8 +274,9 @@ int do_update_h(sph_ctx *c) {
     if (!c->grid_valid || !c->rho_valid) { c->err = "sph_update_h: needs the density of the current positions"; return SPH_ERR_STATE; }
     const PairConst pc = make_pair_const(c);
     { Timed t(c, SPH_K_UPDATE_H); API_HIP(launch_update_h(c, pc)); }
-    // h changed: reaches, neighbour sets, rho all depend on it
+    // h changed: reaches, neighbour sets, rho all depend on it -- but nothing else does (do_density's short path)
     c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
+    c->h_refresh_ok = true;
     return SPH_OK;
 }
 
@@ -631,7 +646,10 @@ static int upload_field_impl(sph_ctx *c, int field, const double *src, int64_t n
     const int f = field;
     API_HIP(launch_scatter_fields(c, 1, &f, 0, n, dsrc));
     API_HIP(hipStreamSynchronize(c->stream));
-    if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) { c->grid_valid = false; c->rho_valid = false; }
+    if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) {
+        c->h_refresh_ok = field == SPH_F_H && (c->grid_valid || c->h_refresh_ok);     // only h is newer than the grid
+        c->grid_valid = false; c->rho_valid = false;
+    }
     if (field <= SPH_F_Z) c->order_valid = false;
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
     return SPH_OK;
@@ -670,6 +688,7 @@ int sph_update_h(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->devi
 int sph_set_owned(sph_ctx *c, int64_t n_owned) {
     if (!c || n_owned < 0 || n_owned > c->n) return SPH_ERR_ARG;
     c->n_owned = n_owned;
+    c->h_refresh_ok = false;
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = false;
     return SPH_OK;
 }
@@ -685,7 +704,8 @@ int sph_scatter_field_dev(sph_ctx *c, int field, int64_t first, int64_t count, c
         return SPH_ERR_ARG;
     DeviceGuard g(c->device);
     API_HIP(launch_scatter_field(c, c->f[field], first, count, d_vals));
-    if (field <= SPH_F_Z || field == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; }
+    if (field <= SPH_F_Z || field == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; c->h_refresh_ok = false; }
+    if (field <= SPH_F_Z) c->order_valid = false;
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO) c->eos_valid = false;
     return SPH_OK;
 }
@@ -714,7 +734,11 @@ int sph_scatter_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_
     DeviceGuard g(c->device);
     API_HIP(launch_scatter_fields(c, nf, fields, first, count, d_vals));
     for (int f = 0; f < nf; f++) {
-        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M || fields[f] == SPH_F_H) { c->grid_valid = false; c->rho_valid = false; }
+        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M || fields[f] == SPH_F_H) {
+            c->h_refresh_ok = fields[f] == SPH_F_H && (c->grid_valid || c->h_refresh_ok);
+            c->grid_valid = false; c->rho_valid = false;
+        }
+        if (fields[f] <= SPH_F_Z) c->order_valid = false;
         if (fields[f] <= SPH_F_ALPHA || fields[f] == SPH_F_RHO || fields[f] == SPH_F_H || fields[f] == SPH_F_OMEGA) c->eos_valid = false;
     }
     return SPH_OK;
@@ -833,6 +857,7 @@ int sph_set_gravity_sources_dev(sph_ctx *c, int64_t n_src, const double *d_xyzm,
     for (int a = 0; a < 6; a++) c->gx_box[a] = n_src > 0 ? lo_hi[a] : 0.0;
     c->gx_keys_valid = false;
     c->tree_valid = false;
+    c->leaf_valid = false;
     c->rates_valid = false;
     if (c->variable) { c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; }      // the leaf boxes change
     return SPH_OK;

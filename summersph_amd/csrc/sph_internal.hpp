@@ -100,6 +100,9 @@ struct sph_ctx {
     void *msort_tmp = nullptr; size_t msort_tmp_bytes = 0;
     double *cell_hmax = nullptr;     // per cell: largest h of its particles
     double *h_new = nullptr;         // scratch for calc_smoothing
+    double *leaf_half = nullptr;     // half edge of every slot's leaf cell (reach = 2 h + this)
+    bool h_refresh_ok = false;       // the only thing newer than the grid is h (sph_update_h / an upload of h)
+    bool leaf_valid = false;         // leaf cells match the current sorted order and (external) octree
     double h_max_glob = 0.0, h_mean = 0.0;
     double root_box[4] = {0, 0, 0, 0};   // octree root centre + edge ([V]:1007-1012)
 
@@ -236,6 +239,7 @@ hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)
 int varh_leaf_build(sph_ctx *c);       // leaf boxes of all particles for the current positions + h
 int varh_nlist_build(sph_ctx *c);
+int varh_refresh_h(sph_ctx *c);        // only h changed: prec, reaches and per-cell max h from the new h
 hipError_t launch_density_v(sph_ctx *c, const PairConst &pc);
 hipError_t launch_eos_only_v(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_v(sph_ctx *c, const PairConst &pc);

@@ -103,7 +103,8 @@ __device__ __forceinline__ int common_levels(uint64_t a, uint64_t b) {
 
 // s = position in key order.  lrec[slot] = {leaf centre, reach = 2 h + edge/2}
 __global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec) {
+                                                     int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec,
+                                                     double *__restrict__ leaf_half) {
     const int64_t s = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
     if (s >= n) return;
     const uint64_t key = keys[s];
@@ -124,12 +125,14 @@ __global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t 
     const uint32_t slot = vals[s];
     const double h = prec[slot].w;
     lrec[slot] = make_double4(cx, cy, cz, 2.0 * h + size / 2.0);          // [V]:380,479
+    leaf_half[slot] = size / 2.0;
 }
 
 // Multi-GPU: the octree is that of ALL GPUs' particles.  gkeys = their sorted path keys (n_glob); a local slot finds its
 // own key there (it is one of them) and takes its leaf level from the neighbours in THAT order.
 __global__ __launch_bounds__(VBLOCK) void leaf_boxes_ext(RootBox rb, const uint64_t *__restrict__ gkeys, int64_t n_glob,
-                                                         int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec) {
+                                                         int64_t n, const double4 *__restrict__ prec, double4 *__restrict__ lrec,
+                                                         double *__restrict__ leaf_half) {
     const int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
     if (i >= n) return;
     const double4 p = prec[i];
@@ -159,6 +162,18 @@ __global__ __launch_bounds__(VBLOCK) void leaf_boxes_ext(RootBox rb, const uint6
         size = size * 0.5;
     }
     lrec[i] = make_double4(cx, cy, cz, 2.0 * p.w + size / 2.0);          // [V]:380,479
+    leaf_half[i] = size / 2.0;
+}
+
+// only h changed since the last build (calc_smoothing at the end of a step: same positions, same sorted order, same
+// leaf cells): new h into the gather records, new reaches 2 h + edge/2 from the stored half edges
+__global__ __launch_bounds__(VBLOCK) void refresh_h_records(int64_t n, const double *__restrict__ h, const double *__restrict__ leaf_half,
+                                                            double4 *__restrict__ prec, double4 *__restrict__ lrec) {
+    const int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double hi = h[i];
+    prec[i].w = hi;
+    lrec[i].w = 2.0 * hi + leaf_half[i];                                  // [V]:380,479
 }
 
 __global__ __launch_bounds__(VBLOCK) void cell_hmax_kernel(const int32_t *__restrict__ cell_start, int64_t ncells,
@@ -660,18 +675,30 @@ int varh_leaf_build(sph_ctx *c) {
         for (int a = 0; a < 3; a++) c->root_box[a] = rb.c[a];
         c->root_box[3] = size;
         { const int st = global_keys_sorted(c); if (st != SPH_OK) return st; }
-        leaf_boxes_ext<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->g_keys_alt, c->gx_n, n, prec, reinterpret_cast<double4 *>(c->lrec));
+        leaf_boxes_ext<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->g_keys_alt, c->gx_n, n, prec, reinterpret_cast<double4 *>(c->lrec), c->leaf_half);
         VH_CHECK(hipGetLastError());
     } else {
         leaf_keys<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, prec, n, c->mkeys, c->mvals);
         VH_CHECK(hipGetLastError());
         size_t tmp = c->msort_tmp_bytes;
         VH_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
-        leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec));
+        leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec), c->leaf_half);
         VH_CHECK(hipGetLastError());
     }
     cell_hmax_kernel<<<dim3((unsigned)((c->grid.ncells + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
         c->cell_start, c->grid.ncells, prec, c->cell_hmax);
+    VH_CHECK(hipGetLastError());
+    return SPH_OK;
+}
+
+// h changed, positions did not: refresh the records that carry h instead of re-sorting and re-deriving the leaf cells
+int varh_refresh_h(sph_ctx *c) {
+    const int64_t n = c->n;
+    if (n == 0) return SPH_OK;
+    refresh_h_records<<<dim3((unsigned)((n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
+        n, c->f[SPH_F_H], c->leaf_half, reinterpret_cast<double4 *>(c->prec), reinterpret_cast<double4 *>(c->lrec));
+    cell_hmax_kernel<<<dim3((unsigned)((c->grid.ncells + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
+        c->cell_start, c->grid.ncells, reinterpret_cast<const double4 *>(c->prec), c->cell_hmax);
     VH_CHECK(hipGetLastError());
     return SPH_OK;
 }
