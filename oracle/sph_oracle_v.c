@@ -211,11 +211,13 @@ void orcv_eos(int n, const double *u, const double *rho, double gamma, double *P
     }
 }
 
-/* gather restatement of [V]:352-432 (+ alpha clean-up [V]:346); a (in/out) holds the gravity terms */
-void orcv_sph_forces(int n, const double *x, const double *y, const double *z, const double *vx, const double *vy, const double *vz,
-                     const double *m, const double *h, const double *rho, const double *omega, const double *P, const double *c,
-                     const double *alpha, const double *lc, const double *ls, int nq, const double *w, const double *dw,
-                     double *ax, double *ay, double *az, double *du, double *dalpha, int nthreads)
+/* gather restatement of [V]:352-432 (+ alpha clean-up [V]:346); a (in/out) holds the gravity terms.
+ * number: the reference's particle numbers (NULL: the array index); they decide whose walk counts for a pair, [V]:383 --
+ * a caller that holds only a subset of the particles (multi-rank tests) passes the global numbers */
+void orcv_sph_forces_num(int n, const double *x, const double *y, const double *z, const double *vx, const double *vy, const double *vz,
+                         const double *m, const double *h, const double *rho, const double *omega, const double *P, const double *c,
+                         const double *alpha, const double *lc, const double *ls, int nq, const double *w, const double *dw,
+                         double *ax, double *ay, double *az, double *du, double *dalpha, const long long *number, int nthreads)
 {
     double hmax = 0.0;
     for (int i = 0; i < n; i++) if (h[i] > hmax) hmax = h[i];
@@ -236,7 +238,8 @@ void orcv_sph_forces(int n, const double *x, const double *y, const double *z, c
                 int j = g.idx[k];
                 if (j == i) continue;
                 /* [V]:383: the walk of the higher-numbered body must reach the lower one's leaf */
-                int ok = (i > j) ? reach(lc, ls, h, j, x[i], y[i], z[i]) : reach(lc, ls, h, i, x[j], y[j], z[j]);
+                const int higher = number ? number[i] > number[j] : i > j;
+                int ok = higher ? reach(lc, ls, h, j, x[i], y[i], z[i]) : reach(lc, ls, h, i, x[j], y[j], z[j]);
                 if (!ok) continue;
                 double n0 = x[i] - x[j], n1 = y[i] - y[j], n2 = z[i] - z[j];          /* [V]:385 */
                 double dr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
@@ -271,6 +274,14 @@ void orcv_sph_forces(int n, const double *x, const double *y, const double *z, c
         dalpha[i] = (t > 0.0 ? t : 0.0) + V_ALPHA_DECAY * ((0.1 - alpha[i]) * c[i] / h[i]);   /* [V]:346 */
     }
     vgrid_free(&g);
+}
+
+void orcv_sph_forces(int n, const double *x, const double *y, const double *z, const double *vx, const double *vy, const double *vz,
+                     const double *m, const double *h, const double *rho, const double *omega, const double *P, const double *c,
+                     const double *alpha, const double *lc, const double *ls, int nq, const double *w, const double *dw,
+                     double *ax, double *ay, double *az, double *du, double *dalpha, int nthreads)
+{
+    orcv_sph_forces_num(n, x, y, z, vx, vy, vz, m, h, rho, omega, P, c, alpha, lc, ls, nq, w, dw, ax, ay, az, du, dalpha, 0, nthreads);
 }
 
 /* calc_smoothing, [V]:515-546.  h_tree = the smoothing lengths the tree holds (those of the last

@@ -270,3 +270,129 @@ class OracleBackend:
 
     def synchronize(self):
         pass
+
+
+class OracleVBackend(OracleBackend):
+    """The variable-h variant ("SUMMER_SPH - Variable.f90") of the stand-in: per-particle h, Omega, the leaf-box neighbour
+    rule with the leaf cells of the octree of ALL ranks' particles (set_gravity_sources), global particle numbers in the
+    pair rule, calc_smoothing.  oracle/sph_oracle_v.c does the arithmetic."""
+    STATE = OracleBackend.STATE + ["h"]
+    variable = True
+
+    def __init__(self, gamma=1.4, eta=1.2, tol=1e-3, max_length=10.0, scale=0.25, nq=2500):
+        from oracle import orc_v
+        super().__init__(h=2.5, nq=nq)
+        self.ov = orc_v
+        self.w, self.dw, _ = orc.tables(nq)
+        self.gamma, self.eta, self.tol, self.max_length, self.scale = gamma, eta, tol, max_length, scale
+        self.params = SimpleNamespace(h=2.5, dt_max=float(np.float32(0.1)), dt_min=float(np.float32(0.0001)))
+        self.number = None
+        self.glob = None            # (positions -> index) of all ranks' particles and their leaf cells
+
+    DERIVED = "rho omega P c ax ay az du dalpha".split()
+
+    def upload(self, state):
+        self.n = self.n_owned = int(state.shape[1])
+        for i, k in enumerate(self.STATE):
+            self.f[k] = np.ascontiguousarray(state[i].cpu().numpy(), dtype=np.float64).copy()
+        for k in self.DERIVED:
+            self.f[k] = np.zeros(self.n)
+        self._ghost_rho = None
+        self.number = None
+
+    def replace_ghosts(self, state):
+        g = state.cpu().numpy()
+        o = self.n_owned
+        for i, k in enumerate(self.STATE):
+            self.f[k] = np.ascontiguousarray(np.concatenate([self.f[k][:o], g[i]]))
+        self.n = o + g.shape[1]
+        for k in self.DERIVED:
+            self.f[k] = np.zeros(self.n)
+        self._ghost_rho = None
+
+    def set_numbers(self, first, numbers):
+        if self.number is None or self.number.size != self.n:
+            self.number = np.zeros(self.n, dtype=np.int64)
+        v = numbers.cpu().numpy().astype(np.int64)
+        self.number[first:first + v.size] = v
+
+    def set_gravity_sources(self, src, lo_hi):
+        s = src.cpu().numpy()
+        X, Y, Z = (np.ascontiguousarray(s[:, k]) for k in range(3))
+        n = X.size
+        lc, ls, root = np.zeros(3 * n), np.zeros(n), np.zeros(4)
+        self.ov.lib().orcv_leaves(C.c_int(n), _p(X), _p(Y), _p(Z), C.c_int(1000), _p(lc), _p(ls), _p(root))
+        self.glob = ({(X[i], Y[i], Z[i]): i for i in range(n)}, lc.reshape(n, 3), ls)
+
+    def _leaves(self):
+        """leaf cells of the local particles in the octree of all particles (looked up by position: the sources are copies)"""
+        f = self.f
+        if self.glob is None:                      # single rank: the local set is the global set
+            lc, ls, root = np.zeros(3 * self.n), np.zeros(self.n), np.zeros(4)
+            self.ov.lib().orcv_leaves(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), C.c_int(1000), _p(lc), _p(ls), _p(root))
+            return lc, ls
+        idx, glc, gls = self.glob
+        k = np.array([idx[(f["x"][i], f["y"][i], f["z"][i])] for i in range(self.n)], dtype=np.int64)
+        return np.ascontiguousarray(glc[k]).reshape(-1), np.ascontiguousarray(gls[k])
+
+    def scatter(self, names, first, vals):
+        v = vals.cpu().numpy()
+        for i, name in enumerate(names):
+            self.f[name][first:first + v.shape[1]] = v[i]
+        if "rho" in names:          # ghosts keep the rho / Omega their owner sent
+            self._ghost_rho = (self.f["rho"][self.n_owned:].copy(), self.f["omega"][self.n_owned:].copy())
+
+    def density(self):
+        f = self.f
+        self.lc, self.ls = self._leaves()
+        self.h_tree = f["h"].copy()
+        self.ov.lib().orcv_density(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["m"]), _p(f["h"]), _p(self.lc), _p(self.ls),
+                                   C.c_int(self.nq), _p(self.w), _p(self.dw), _p(f["rho"]), _p(f["omega"]), C.c_int(1))
+        if self._ghost_rho is not None:
+            f["rho"][self.n_owned:], f["omega"][self.n_owned:] = self._ghost_rho
+        self.refresh_eos()
+
+    def refresh_eos(self):
+        f = self.f
+        self.ov.lib().orcv_eos(C.c_int(self.n), _p(f["u"]), _p(f["rho"]), C.c_double(self.gamma), _p(f["P"]), _p(f["c"]))
+
+    def forces(self):
+        f, s = self.f, self.s
+        ns = s["x"].size
+        sax, say, saz = np.zeros(ns), np.zeros(ns), np.zeros(ns)
+        orc.lib().orc_sink_gravity(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["m"]), C.c_int(ns),
+                                   _p(s["x"]), _p(s["y"]), _p(s["z"]), _p(s["m"]), _p(f["ax"]), _p(f["ay"]), _p(f["az"]),
+                                   _p(sax), _p(say), _p(saz))
+        G = orc.lib().orc_G()
+        o = slice(0, self.n_owned)
+        for i in range(ns):                        # sink side: owned particles only
+            v = np.stack([f["x"][o] - s["x"][i], f["y"][o] - s["y"][i], f["z"][o] - s["z"][i]])
+            d3 = np.sqrt((v ** 2).sum(0)) ** 3
+            s["ax"][i], s["ay"][i], s["az"][i] = (f["m"][o] * (G * v / d3)).sum(1)
+        num = self.number if self.number is not None else np.arange(self.n, dtype=np.int64)
+        num = np.ascontiguousarray(num, dtype=np.int64)
+        self.ov.lib().orcv_sph_forces_num(
+            C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["vx"]), _p(f["vy"]), _p(f["vz"]), _p(f["m"]), _p(f["h"]),
+            _p(f["rho"]), _p(f["omega"]), _p(f["P"]), _p(f["c"]), _p(f["alpha"]), _p(self.lc), _p(self.ls), C.c_int(self.nq),
+            _p(self.w), _p(self.dw), _p(f["ax"]), _p(f["ay"]), _p(f["az"]), _p(f["du"]), _p(f["dalpha"]),
+            num.ctypes.data_as(C.POINTER(C.c_longlong)), C.c_int(1))
+
+    def forces_boundary(self):
+        self.forces()
+
+    def update_h(self):
+        """calc_smoothing for the owned particles on the tree of the last evaluation (the ghosts' new h comes from their owners)"""
+        f = self.f
+        h_new = f["h"].copy()
+        rho, om = f["rho"].copy(), f["omega"].copy()
+        self.ov.lib().orcv_update_h(C.c_int(self.n), _p(f["x"]), _p(f["y"]), _p(f["z"]), _p(f["m"]), _p(h_new), _p(rho), _p(om),
+                                    _p(self.lc), _p(self.ls), C.c_int(self.nq), _p(self.w), _p(self.dw), C.c_double(self.eta),
+                                    C.c_double(self.tol), C.c_double(self.max_length), C.c_int(1))
+        o = self.n_owned
+        f["h"][:o] = h_new[:o]
+
+    def _dt_candidate(self):
+        f, o = self.f, self.n_owned
+        a = {k: np.ascontiguousarray(f[k][:o]) for k in "vx vy vz ax ay az u du c h".split()}
+        return self.ov.lib().orcv_dt_candidate(C.c_int(o), _p(a["vx"]), _p(a["vy"]), _p(a["vz"]), _p(a["ax"]), _p(a["ay"]),
+                                               _p(a["az"]), _p(a["u"]), _p(a["du"]), _p(a["c"]), _p(a["h"]), C.c_double(self.scale))

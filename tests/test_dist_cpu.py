@@ -156,3 +156,43 @@ def test_two_sinks_across_ranks(tmp_path):
         assert np.max(np.abs(p["sx"] - g["sph_s3_sx"])) <= 1e-12 and np.array_equal(p["svx"], parts[0]["svx"])
     for f in FIELDS:
         assert rel_err(merged[f], g["sph_s3_" + f]) <= 1e-11, f
+
+
+def _worker_var(rank, world, port, nsteps, outdir, ic_rows, params):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from dist_backend import OracleVBackend
+    from summersph_amd import ic
+    from summersph_amd.dist import DistSim, slab_bounds
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    gas, sinks = ic.split_rows(ic_rows)
+    bounds = slab_bounds(gas["x"], world)
+    sel = np.searchsorted(bounds, gas["x"], side="right") == rank
+    mine = {k: v[sel] for k, v in gas.items()}
+    mine["gid"] = np.nonzero(sel)[0]
+    gamma, eta, tol, maxlen, scale = (float(v) for v in params)
+    sim = DistSim(OracleVBackend(gamma, eta, tol, maxlen, scale), mine, sinks, bounds, migrate_every=2)
+    dts = [1e-2]
+    for _ in range(nsteps):
+        dts.append(sim.step(dts[-1]))
+    st = sim.gather_state()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), dts=np.array(dts), ghosts=sim.stats["ghosts"], h=sim.owned[9].cpu().numpy(), **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_variable_h_across_ranks_vs_reference_fixture(tmp_path):
+    """the variable-h orchestration (h and global particle numbers in the ghost exchange, leaf cells from the octree of all
+    particles, rho + Omega refresh, calc_smoothing per rank) on 2 CPU ranks against the real reference's trajectory"""
+    g = load_golden("discv3000_traj")
+    mp.spawn(_worker_var, args=(2, _free_port(), 5, str(tmp_path), g["ic"], g["params"]), nprocs=2, join=True)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(2)]
+    gid = np.concatenate([p["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(gid.size))
+    order = np.argsort(gid)
+    for p in parts:
+        assert list(p["dts"]) == list(g["sph_dt_seq"]) and p["ghosts"] > 0
+    for f in FIELDS + ["h"]:
+        assert rel_err(np.concatenate([p[f] for p in parts])[order], g["sph_s5_" + f]) <= 1e-10, f
