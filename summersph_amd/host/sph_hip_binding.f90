@@ -18,6 +18,12 @@ module sph_hip_binding
   public :: SPH_F_H, SPH_F_OMEGA
   public :: SPH_FLAG_REUSE_DENSITY, SPH_FLAG_VARIABLE_H, SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL
   public :: SPH_FLAG_SINK_CREATION, sph_sink_count, sph_get_sink_radii
+  ! multi-GPU building blocks (device pointers as type(c_ptr), e.g. from hipMalloc or an MPI library's GPU buffers)
+  public :: sph_set_owned, sph_set_rank, sph_reserve, sph_owned_bbox, sph_select_boxes, sph_selected_ids_dev
+  public :: sph_replace_ghosts_dev, sph_gather_fields_dev, sph_scatter_fields_dev, sph_refresh_eos_ghosts
+  public :: sph_set_boundary_boxes, sph_forces_part, sph_set_dt, sph_get_dt, sph_kick_devdt, sph_drift_devdt
+  public :: sph_dt_candidate_dev, sph_pack_partials_dev, sph_apply_partials_dev, sph_set_gravity_sources_dev
+  public :: SPH_PARTIALS
   public :: c_message
 
   integer(c_int), parameter :: SPH_OK = 0
@@ -28,6 +34,7 @@ module sph_hip_binding
   integer(c_int), parameter :: SPH_F_H = 17, SPH_F_OMEGA = 18
   integer(c_int32_t), parameter :: SPH_FLAG_REUSE_DENSITY = 1, SPH_FLAG_VARIABLE_H = 2, SPH_FLAG_SELF_GRAVITY = 16
   integer(c_int32_t), parameter :: SPH_FLAG_ACCRETE_CULL = 32, SPH_FLAG_SINK_CREATION = 64
+  integer(c_int32_t), parameter :: SPH_PARTIALS = 199
 
   type, bind(C) :: sph_params
     real(c_double) :: h, gamma, gamma_m1
@@ -235,6 +242,112 @@ module sph_hip_binding
     integer(c_int) function sph_synchronize(ctx) bind(C, name='sph_synchronize')
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
+    end function
+
+    ! ---- one context per GPU: owned particles + ghost copies, exchanged by the caller (MPI, RCCL, ...) -------------
+    integer(c_int) function sph_set_owned(ctx, n_owned) bind(C, name='sph_set_owned')
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: n_owned
+    end function
+    integer(c_int) function sph_set_rank(ctx, rank, nranks) bind(C, name='sph_set_rank')
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: rank, nranks
+    end function
+    integer(c_int) function sph_reserve(ctx, n_slots) bind(C, name='sph_reserve')
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: n_slots
+    end function
+    integer(c_int) function sph_owned_bbox(ctx, lo_hi, d_lo_hi) bind(C, name='sph_owned_bbox')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, d_lo_hi
+      real(c_double), intent(out) :: lo_hi(6)
+    end function
+    integer(c_int) function sph_select_boxes(ctx, nbox, boxes, counts) bind(C, name='sph_select_boxes')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nbox
+      real(c_double), intent(in) :: boxes(6, *)
+      integer(c_int64_t), intent(out) :: counts(*)
+    end function
+    integer(c_int) function sph_selected_ids_dev(ctx, box, count, d_ids) bind(C, name='sph_selected_ids_dev')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx, d_ids
+      integer(c_int32_t), value :: box
+      integer(c_int64_t), value :: count
+    end function
+    integer(c_int) function sph_replace_ghosts_dev(ctx, count, d_state) bind(C, name='sph_replace_ghosts_dev')
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx, d_state
+      integer(c_int64_t), value :: count
+    end function
+    integer(c_int) function sph_gather_fields_dev(ctx, nf, fields, count, d_ids, d_out) bind(C, name='sph_gather_fields_dev')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx, d_ids, d_out
+      integer(c_int32_t), value :: nf
+      integer(c_int32_t), intent(in) :: fields(*)
+      integer(c_int64_t), value :: count
+    end function
+    integer(c_int) function sph_scatter_fields_dev(ctx, nf, fields, first, count, d_vals) bind(C, name='sph_scatter_fields_dev')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx, d_vals
+      integer(c_int32_t), value :: nf
+      integer(c_int32_t), intent(in) :: fields(*)
+      integer(c_int64_t), value :: first, count
+    end function
+    integer(c_int) function sph_refresh_eos_ghosts(ctx) bind(C, name='sph_refresh_eos_ghosts')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function sph_set_boundary_boxes(ctx, nbox, boxes) bind(C, name='sph_set_boundary_boxes')
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nbox
+      real(c_double), intent(in) :: boxes(6, *)
+    end function
+    integer(c_int) function sph_forces_part(ctx, part) bind(C, name='sph_forces_part')
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: part
+    end function
+    integer(c_int) function sph_set_dt(ctx, dt, t) bind(C, name='sph_set_dt')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), value :: dt, t
+    end function
+    integer(c_int) function sph_get_dt(ctx, dt, t) bind(C, name='sph_get_dt')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: dt, t
+    end function
+    integer(c_int) function sph_kick_devdt(ctx) bind(C, name='sph_kick_devdt')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function sph_drift_devdt(ctx) bind(C, name='sph_drift_devdt')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function sph_dt_candidate_dev(ctx) bind(C, name='sph_dt_candidate_dev')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function sph_pack_partials_dev(ctx, d_out) bind(C, name='sph_pack_partials_dev')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, d_out
+    end function
+    integer(c_int) function sph_apply_partials_dev(ctx, d_all, nranks, stride, apply_dt) bind(C, name='sph_apply_partials_dev')
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: ctx, d_all
+      integer(c_int32_t), value :: nranks, stride, apply_dt
+    end function
+    integer(c_int) function sph_set_gravity_sources_dev(ctx, n_src, d_xyzm, lo_hi) bind(C, name='sph_set_gravity_sources_dev')
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ctx, d_xyzm
+      integer(c_int64_t), value :: n_src
+      real(c_double), intent(in) :: lo_hi(6)
     end function
   end interface
 
