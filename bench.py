@@ -271,7 +271,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed {args.backend})",
                        "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
-            "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else "forces_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else ("forces_wt" if st.tile_fit_pct >= 90 else "forces_kernel"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
                          "note": "compulsory HBM traffic is tiny for this path; the pair loop is bound by the L1/TA gather "

@@ -88,6 +88,8 @@ typedef struct sph_params {
 #define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
                                    results up to summation order; measured SLOWER than the default
                                    direct gathers on MI355X, kept for tuning  */
+#define SPH_FLAG_NO_WHOLE_TILE 128 /* fixed-h path: density/forces with the memory gathers of pairs.hip only, never the
+                                   whole-tile kernels of tiled.hip (bitwise the same results); A/B measurements */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
                                     change since the last one (bitwise the same rho); OFF by
                                     default: the reference recomputes it, [F]:896,908 */
@@ -121,6 +123,9 @@ typedef struct sph_stats {
     int32_t grid_dim[3];    /* cells along x, y, z                                        */
     int32_t nlist_capacity; /* neighbour slots per particle currently allocated           */
     int32_t nlist_max;      /* largest neighbour count found at the last build            */
+    int32_t tile_fit_pct;   /* fixed h: workgroups (%) whose neighbour intervals fit the LDS tile of the
+                               whole-tile pair kernels at the last build; those kernels run when >= 90;
+                               -1: kernels off (flags, variable h)                        */
     double  nlist_mean;     /* mean neighbour count (pairs inside 2h, self excluded)      */
     int64_t grid_builds, nlist_builds, density_passes, force_passes;
     int64_t device_bytes;   /* HBM held by the context                                    */

@@ -24,6 +24,7 @@ FLAG_LDS_TILE_EVAL = 8
 FLAG_SELF_GRAVITY = 16
 FLAG_ACCRETE_CULL = 32
 FLAG_SINK_CREATION = 64
+FLAG_NO_WHOLE_TILE = 128
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
@@ -54,7 +55,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_cells", C.c_int64), ("grid_dim", C.c_int32 * 3),
-                ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("nlist_mean", C.c_double),
+                ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("tile_fit_pct", C.c_int32), ("nlist_mean", C.c_double),
                 ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
                 ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double)]
 

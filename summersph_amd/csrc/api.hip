@@ -195,7 +195,8 @@ int do_density(sph_ctx *c) {
     if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
         API_HIP(c->variable ? launch_eos_only_v(c, pc) : launch_eos_only(c, pc));
     } else {
-        API_HIP(c->variable ? launch_density_v(c, pc) : (c->tiled_eval ? launch_density_tiled(c, pc) : launch_density(c, pc)));
+        API_HIP(c->variable ? launch_density_v(c, pc) : (c->tiled_eval ? launch_density_tiled(c, pc)
+                                                                   : ((c->whole_tile && c->wt_ok) ? launch_density_wt(c, pc) : launch_density(c, pc))));
         c->density_passes++;
     }
     c->rho_valid = true; c->eos_valid = true;
@@ -211,7 +212,8 @@ int do_forces(sph_ctx *c) {
         API_HIP(launch_gravity(c));
     }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc) : launch_forces(c, pc))); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc)
+                                                                   : ((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc)))); }
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -226,13 +228,13 @@ int do_forces_part(sph_ctx *c, int part) {
     if (part == 1) {
         if (!c->wave_class_valid) { API_HIP(launch_classify_waves(c)); c->wave_class_valid = true; }
         { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-        { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc, 1)); }
+        { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 1) : launch_forces(c, pc, 1)); }
         c->interior_done = true;
         c->rates_valid = false;
         return SPH_OK;
     }
     if (!c->interior_done) { c->err = "sph_forces_part: part 2 before part 1"; return SPH_ERR_STATE; }
-    { Timed t(c, SPH_K_FORCES); API_HIP(launch_forces(c, pc, 2)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 2) : launch_forces(c, pc, 2)); }
     c->interior_done = false;
     c->force_passes++;
     c->rates_valid = true;
@@ -416,6 +418,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     c->gravity = (p->flags & SPH_FLAG_SELF_GRAVITY) != 0;
     c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
     c->tiled_eval = c->tiled && (p->flags & SPH_FLAG_LDS_TILE_EVAL) != 0;
+    c->whole_tile = c->tiled && !c->tiled_eval && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0;
     c->packed_list = c->tiled;
     c->device = device;
     DeviceGuard g(device);
@@ -425,7 +428,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 640 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
     std::memset(c->h_pinned, 0, 640 * sizeof(double));
     if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 32, "bbox")) != SPH_OK) return fail(st);
-    if ((st = ctx_alloc(c, &c->d_flags, 4, "flags")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->d_flags, 8, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->grav_tab, (size_t)p->nq + 1, "softening table")) != SPH_OK) return fail(st);
@@ -610,6 +613,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
     o->n = c->n; o->n_cells = c->grid.ncells;
     for (int a = 0; a < 3; a++) o->grid_dim[a] = c->grid.dim[a];
     o->nlist_capacity = c->nl_cap; o->nlist_max = c->nl_max;
+    o->tile_fit_pct = c->whole_tile ? c->wt_fit_pct : -1;
     o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
     o->density_passes = c->density_passes; o->force_passes = c->force_passes;
     o->device_bytes = c->device_bytes;

@@ -92,6 +92,9 @@ struct sph_ctx {
     bool variable = false;
     bool tiled = true;               // fixed-h: LDS-staged neighbour-list build (tiled.hip) unless SPH_FLAG_NO_LDS_TILES
     bool tiled_eval = false;         // fixed-h: LDS-staged density/forces too (SPH_FLAG_LDS_TILE_EVAL; slower)
+    bool whole_tile = false;         // fixed-h: density/forces read the neighbours' {x,y,z,m} from one LDS tile per workgroup (tiled.hip)
+    bool wt_ok = false;              // ... and the last list build found that the workgroups' intervals fit the tile
+    int32_t wt_fit_pct = -1;         // percentage of workgroups that fit (-1: kernels off)
     bool packed_list = true;         // list layout: 4-packed (tiled build) or wave-strided dwords (nlist_kernel)
     double *prec = nullptr;          // 4 doubles: x y z h        (neighbour-list build)
     double *lrec = nullptr;          // 4 doubles: leaf centre x y z, reach = 2h + leaf_edge/2 (<0: unresolved)
@@ -220,6 +223,8 @@ hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, in
 int nlist_build_tiled(sph_ctx *c);
 hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
+hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc);
+hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part);
 // self-gravity (gravity.hip)
 hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
 int gravity_tree_build(sph_ctx *c);

@@ -47,7 +47,7 @@ module sph_hip_binding
   type, bind(C) :: sph_stats
     integer(c_int64_t) :: n, n_cells
     integer(c_int32_t) :: grid_dim(3)
-    integer(c_int32_t) :: nlist_capacity, nlist_max
+    integer(c_int32_t) :: nlist_capacity, nlist_max, tile_fit_pct
     real(c_double) :: nlist_mean
     integer(c_int64_t) :: grid_builds, nlist_builds, density_passes, force_passes, device_bytes
     real(c_double) :: nlist_wave_mean

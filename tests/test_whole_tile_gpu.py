@@ -1,0 +1,95 @@
+"""The whole-tile pair kernels (tiled.hip: neighbours' {x,y,z,m} from one LDS tile per workgroup, chosen per list build
+and per workgroup) against the direct-gather kernels of pairs.hip (SPH_FLAG_NO_WHOLE_TILE).  Both perform the same
+operations in the same order, so the comparison is bitwise; parity with the reference is what test_parity_gpu.py checks
+(it runs whichever kernels the context picks)."""
+import numpy as np
+import pytest
+
+from summersph_amd import ic
+
+pytestmark = pytest.mark.gpu
+FIELDS = "rho P c ax ay az du dalpha".split()
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from summersph_amd import capi as m
+    m.load()
+    return m
+
+
+def evaluate(capi, gas, sinks, flags, steps=0):
+    ctx = capi.Context(device=0, flags=flags)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    if steps:
+        ctx.run(steps, 1e-2, 0.0)
+        out = {f: ctx.field(f) for f in "x y z vx vy vz u alpha".split()}
+    else:
+        ctx.density(); ctx.forces()
+        out = {f: ctx.field(f) for f in FIELDS}
+    st = ctx.stats()
+    ctx.close()
+    return out, st
+
+
+def stirred_disc(n, seed=202):
+    gas, sinks = ic.split_rows(ic.keplerian_disc(n, seed=seed, nngb=85.0))
+    rng = np.random.default_rng(3)
+    gas["vx"] = gas["vx"] + rng.normal(0.0, 0.05, n)          # viscosity switches on
+    gas["alpha"] = np.full(n, 0.3)
+    return gas, sinks
+
+
+def test_thin_disc_runs_from_the_tile_and_matches_bitwise(capi):
+    gas, sinks = stirred_disc(200_000)
+    a, sa = evaluate(capi, gas, sinks, 0)
+    b, sb = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE)
+    assert sa.tile_fit_pct >= 90 and sb.tile_fit_pct == -1
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_ragged_size_and_trajectory(capi):
+    gas, sinks = stirred_disc(70_001, seed=5)                  # last workgroup partly filled, last wave ragged
+    a, sa = evaluate(capi, gas, sinks, 0, steps=3)
+    b, _ = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE, steps=3)
+    assert sa.tile_fit_pct >= 90
+    for f in a:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_thick_domain_keeps_the_gather_kernels(capi):
+    # a cube of 40^3 cells' worth of particles: the three intervals of a workgroup span whole columns, nothing fits
+    rng = np.random.default_rng(8)
+    n = 150_000
+    gas = {k: np.zeros(n) for k in "x y z vx vy vz u m alpha".split()}
+    for k in "xyz":
+        gas[k] = rng.uniform(0.0, 120.0, n)
+    gas["u"][:] = 0.25; gas["m"][:] = 1e-4; gas["alpha"][:] = 0.1
+    gas["vx"] = rng.normal(0.0, 0.05, n)
+    sinks = {k: np.zeros(0) for k in "x y z vx vy vz m".split()}
+    a, sa = evaluate(capi, gas, sinks, 0)
+    b, _ = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE)
+    assert 0 <= sa.tile_fit_pct < 90
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_workgroups_that_do_not_fit_fall_back_inside_the_kernel(capi):
+    # thin disc plus a thick blob in a corner of it: a few per cent of the workgroups exceed the tile and take the
+    # gather loop inside the whole-tile kernels, the rest read LDS -- in the same launch
+    gas, sinks = stirred_disc(200_000, seed=9)
+    rng = np.random.default_rng(10)
+    nb = 12_000
+    blob = {k: np.zeros(nb) for k in gas if isinstance(gas[k], np.ndarray)}
+    r_out = float(np.max(np.hypot(gas["x"], gas["y"])))
+    blob["x"] = 0.5 * r_out + rng.uniform(-20.0, 20.0, nb)
+    blob["y"] = rng.uniform(-20.0, 20.0, nb)
+    blob["z"] = rng.uniform(-20.0, 20.0, nb)
+    blob["u"][:] = 0.25; blob["m"][:] = gas["m"][0]; blob["alpha"][:] = 0.3
+    both = {k: np.concatenate([gas[k], blob[k]]) for k in blob}
+    a, sa = evaluate(capi, both, sinks, 0)
+    b, _ = evaluate(capi, both, sinks, capi.FLAG_NO_WHOLE_TILE)
+    assert 90 <= sa.tile_fit_pct < 100
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
