@@ -252,7 +252,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "r01_forces_traffic.json")
         if os.path.exists(tf) and world == 1 and not variable and args.ic == "disc":
             rec = json.load(open(tf))
-            if rec.get("workload_particles") == args.n:
+            if rec.get("workload_particles") == args.n and rec.get("kernel", "").startswith("forces_wt" if st.tile_fit_pct >= 90 else "forces_kernel"):
                 traffic, traffic_src = rec["traffic_bytes_per_launch"], rec.get("source")
         wl = ((f"thin Keplerian ring (r ~ N(r0, 0.05 r0)), " if args.ic == "ring" and not variable else "uniform Keplerian disc, ")
               + f"{args.n} gas particles + 1 sink per GPU, "

@@ -418,7 +418,9 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     c->gravity = (p->flags & SPH_FLAG_SELF_GRAVITY) != 0;
     c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
     c->tiled_eval = c->tiled && (p->flags & SPH_FLAG_LDS_TILE_EVAL) != 0;
-    c->whole_tile = c->tiled && !c->tiled_eval && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0;
+    // whole-tile kernels: 116 KB tile + the kernel table must fit the 160 KB of LDS (nq <= ~5500)
+    c->whole_tile = c->tiled && !c->tiled_eval && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0 &&
+                    (size_t)((p->nq + 2) & ~1) * sizeof(double) + (size_t)WT_TILE_RECORDS * 32 + 1024 <= (size_t)160 * 1024;
     c->packed_list = c->tiled;
     c->device = device;
     DeviceGuard g(device);

@@ -223,6 +223,7 @@ hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, in
 int nlist_build_tiled(sph_ctx *c);
 hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
+constexpr int WT_TILE_RECORDS = 3712;     // whole-tile kernels: {x,y,z,m} records per LDS tile (116 KB; + the kernel table <= 160 KB)
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part);
 // self-gravity (gravity.hip)

@@ -32,7 +32,7 @@ namespace {
 
 constexpr int TB = 256;              // threads per workgroup = targets per workgroup
 constexpr int WT_BS = 1024;         // whole-tile kernels: threads (= targets) per workgroup, one workgroup per CU
-constexpr int WT_CAP = 3712;        // ... and records per tile (116 KB of {x,y,z,m}; + 40 KB kernel table)
+constexpr int WT_CAP = WT_TILE_RECORDS;   // ... and records per tile (116 KB of {x,y,z,m}; + 40 KB kernel table)
 constexpr int T_NL = 512;            // staged records per chunk: neighbour-list build (32 B each)
 // density / forces: chunk size and where the kernel table lives are template parameters, chosen by
 // measurement (launch_*_tiled): TABLDS = table staged in LDS (40 KB, limits workgroups per CU),
