@@ -12,9 +12,11 @@
 //   cell_table               -> cell_start[c] = first sorted slot with key >= c
 //   reorder                  -> gathers the 9 state arrays + ids into sorted order and writes
 //                               the 32-byte density gather record {x,y,z,m}
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <cmath>
 #include <utility>
@@ -108,6 +110,73 @@ __global__ __launch_bounds__(256) void cell_keys(GridDesc g, const double *__res
     const bool dead = i < dead_below && orig[i] >= n_owned;
     keys[i] = dead ? (uint32_t)g.ncells : cell_key(g, x[i], y[i], z[i], cc);
     vals[i] = (uint32_t)i;
+}
+
+// ---- counting sort by cell (the default; the radix sort below remains for grids with far more cells than particles) ----
+// The sorted order wanted is that of a STABLE sort of (cell key, slot): cells ascending, within a cell the slots in their
+// previous order.  keys + histogram -> exclusive scan = cell table -> scatter with a per-cell cursor (arrival order, not
+// reproducible) -> every entry is moved to its rank among the entries of its cell (reproducible again).
+// ~70 us at 1e6 particles against ~165 us for rocprim's 21-launch merge sort of the same pairs + the table search.
+// The slots are nearly sorted already (last step's order), so the lanes of a wave hold a few runs of equal keys: one atomic
+// per run instead of one per lane (42 -> ~10 us for the histogram, 60 -> ~15 us for the scatter at 1e6 particles).
+// Returns this lane's offset within its run and, for the run's first lane, the run length (0 for the others).
+__device__ __forceinline__ int run_of_equal_keys(uint32_t k, bool valid, int &run_len, int &head_lane) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t prev = (uint32_t)__shfl_up((int)k, 1, 64);
+    const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 64) != 0;
+    const bool head = valid && (lane == 0 || !pvalid || prev != k);
+    // a run ends where the next head starts or where the valid lanes end
+    const uint64_t heads = __ballot(head), ends = heads | ~__ballot(valid);
+    const uint64_t below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));          // heads at or below this lane
+    head_lane = below ? 63 - __clzll((long long)below) : lane;
+    const uint64_t above = lane == 63 ? 0ull : (ends >> (lane + 1));                           // first boundary above this lane
+    const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+    run_len = head ? next - lane : 0;
+    return lane - head_lane;
+}
+
+__global__ __launch_bounds__(256) void cell_keys_count(GridDesc g, const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, int64_t n, uint32_t *__restrict__ keys,
+                                                       int32_t *__restrict__ count, const int32_t *__restrict__ orig,
+                                                       int32_t n_owned, int64_t dead_below) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t k = 0;
+    if (valid) {
+        int cc[3];
+        const bool dead = i < dead_below && orig[i] >= n_owned;
+        k = dead ? (uint32_t)g.ncells : cell_key(g, x[i], y[i], z[i], cc);
+        keys[i] = k;
+    }
+    int run_len, head_lane;
+    run_of_equal_keys(k, valid, run_len, head_lane);
+    if (run_len > 0) atomicAdd(&count[k], run_len);
+}
+
+__global__ __launch_bounds__(256) void cell_scatter(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ cell_start,
+                                                    int32_t *__restrict__ fill, uint32_t *__restrict__ slots) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t k = valid ? keys[i] : 0u;
+    int run_len, head_lane;
+    const int off = run_of_equal_keys(k, valid, run_len, head_lane);
+    int base = 0;
+    if (run_len > 0) base = cell_start[k] + atomicAdd(&fill[k], run_len);
+    base = __shfl(base, head_lane, 64);
+    if (valid) slots[base + off] = (uint32_t)i;
+}
+
+// p < n_live: entry slots[p] of cell k goes to cell_start[k] + (number of entries of the cell that are smaller)
+__global__ __launch_bounds__(256) void cell_rank(const uint32_t *__restrict__ keys, int64_t n_live, const int32_t *__restrict__ cell_start,
+                                                 const uint32_t *__restrict__ slots, uint32_t *__restrict__ sorted) {
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_live) return;
+    const uint32_t v = slots[p];
+    const uint32_t k = keys[v];
+    const int s = cell_start[k], e = cell_start[k + 1];
+    int rank = 0;
+    for (int q = s; q < e; q++) rank += slots[q] < v ? 1 : 0;
+    sorted[s + rank] = v;
 }
 
 // cell_start[c] = lower_bound(sorted keys, c), c in [0, ncells]
@@ -334,10 +403,11 @@ int grid_rebuild(sph_ctx *c) {
     g.s[0] = s[0]; g.s[1] = s[1]; g.s[2] = s[2];
     c->grid = g;
 
-    if (g.ncells + 1 > c->cell_cap) {
-        ctx_free(c, c->cell_start);
-        c->cell_cap = (g.ncells + 1) + (g.ncells + 1) / 4;
+    if (g.ncells + 2 > c->cell_cap) {
+        ctx_free(c, c->cell_start); ctx_free(c, c->cell_fill);
+        c->cell_cap = (g.ncells + 2) + (g.ncells + 2) / 4;
         if (ctx_alloc(c, &c->cell_start, (size_t)c->cell_cap, "cell table") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
+        if (ctx_alloc(c, &c->cell_fill, (size_t)c->cell_cap, "cell cursors") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
         if (c->variable) {
             ctx_free(c, c->cell_hmax);
             if (ctx_alloc(c, &c->cell_hmax, (size_t)c->cell_cap, "cell hmax") != SPH_OK) return SPH_ERR_NOMEM;
@@ -346,16 +416,38 @@ int grid_rebuild(sph_ctx *c) {
 
     // ---- keys, sort, cell table ---------------------------------------------------------
     const unsigned gb = (unsigned)((std::max<int64_t>(n, 1) + 255) / 256);
-    cell_keys<<<dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->keys,
-                                                                        c->vals, c->orig, (int32_t)c->n_owned, c->dead_below);
-    GR_CHECK(hipGetLastError());
-    unsigned bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) < g.ncells + (swap ? 1 : 0)) bits++;
-    size_t tmp = c->sort_tmp_bytes;
-    GR_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->keys, c->keys_alt, c->vals, c->vals_alt, (size_t)ns, 0u, bits, st));
-    c->n_slots = n; c->dead_below = 0;     // the replaced ghosts sorted behind the n live entries and are dropped here
-    cell_table<<<dim3((unsigned)((g.ncells + 1 + 255) / 256)), dim3(256), 0, st>>>(c->keys_alt, n, g.ncells, c->cell_start);
-    GR_CHECK(hipGetLastError());
+    const unsigned gbs = (unsigned)((ns + 255) / 256);
+    static const bool force_radix = getenv("SPH_SORT_RADIX") != nullptr;             // A/B switch
+    size_t scan_tmp = 0;
+    bool counting = !force_radix && g.ncells <= 4 * ns + 1000000;
+    if (counting) {
+        GR_CHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->cell_start, c->cell_start, 0, (size_t)(g.ncells + 2), rocprim::plus<int32_t>(), st));
+        counting = scan_tmp <= c->sort_tmp_bytes;
+    }
+    if (counting) {
+        GR_CHECK(hipMemsetAsync(c->cell_start, 0, sizeof(int32_t) * (size_t)(g.ncells + 2), st));
+        GR_CHECK(hipMemsetAsync(c->cell_fill, 0, sizeof(int32_t) * (size_t)(g.ncells + 1), st));
+        cell_keys_count<<<dim3(gbs), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->keys, c->cell_start,
+                                                        c->orig, (int32_t)c->n_owned, c->dead_below);
+        GR_CHECK(hipGetLastError());
+        // in place: cell_start[c] = first sorted slot of cell c; [ncells] = live particles; the replaced ghosts sort behind them
+        GR_CHECK(rocprim::exclusive_scan(c->sort_tmp, scan_tmp, c->cell_start, c->cell_start, 0, (size_t)(g.ncells + 2), rocprim::plus<int32_t>(), st));
+        cell_scatter<<<dim3(gbs), dim3(256), 0, st>>>(c->keys, ns, c->cell_start, c->cell_fill, c->vals);
+        cell_rank<<<dim3(gb), dim3(256), 0, st>>>(c->keys, n, c->cell_start, c->vals, c->vals_alt);
+        GR_CHECK(hipGetLastError());
+        c->n_slots = n; c->dead_below = 0;
+    } else {
+        cell_keys<<<dim3(gbs), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->keys,
+                                                  c->vals, c->orig, (int32_t)c->n_owned, c->dead_below);
+        GR_CHECK(hipGetLastError());
+        unsigned bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < g.ncells + (swap ? 1 : 0)) bits++;
+        size_t tmp = c->sort_tmp_bytes;
+        GR_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->keys, c->keys_alt, c->vals, c->vals_alt, (size_t)ns, 0u, bits, st));
+        c->n_slots = n; c->dead_below = 0;     // the replaced ghosts sorted behind the n live entries and are dropped here
+        cell_table<<<dim3((unsigned)((g.ncells + 1 + 255) / 256)), dim3(256), 0, st>>>(c->keys_alt, n, g.ncells, c->cell_start);
+        GR_CHECK(hipGetLastError());
+    }
 
     // ---- reorder state into sorted slots --------------------------------------------------
     ReorderArgs ra{};
