@@ -395,11 +395,16 @@ int grid_rebuild(sph_ctx *c) {
     }
     if (ncell_d >= 2147483647.0) { c->err = "cell grid exceeds 2^31 cells"; return SPH_ERR_GRID; }
     g.ncells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
-    // axis permutation: fewest cells fastest
+    // axis permutation: the axis with the fewest cells runs fastest (a column of cells is short: the thin direction of a
+    // disc), the LONGEST of the other two is the middle one.  Rows are then as long as possible, a workgroup of consecutive
+    // particles rarely wraps from one row into the next, and its three candidate intervals (tiled.hip) stay a few columns
+    // wide -- also in the narrow x-slabs of a multi-GPU run, where the short axis in the middle would make every
+    // interval span whole rows
     int s[3] = {0, 1, 2};
     for (int i = 0; i < 3; i++)
         for (int j = i + 1; j < 3; j++)
             if (g.dim[s[j]] < g.dim[s[i]]) std::swap(s[i], s[j]);
+    std::swap(s[1], s[2]);
     g.s[0] = s[0]; g.s[1] = s[1]; g.s[2] = s[2];
     c->grid = g;
 

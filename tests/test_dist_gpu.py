@@ -41,7 +41,8 @@ def _worker(rank, world, port, nsteps, outdir, ic_rows, flags=0):
     st = sim.gather_state()
     s = sim.be.get_sinks()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), dts=np.array(dts), ghosts=sim.stats["ghosts"],
-             migrated=sim.stats["migrated"], sx=s["x"], svx=s["vx"], **st)
+             migrated=sim.stats["migrated"], sx=s["x"], svx=s["vx"], tile_fit_pct=sim.be.ctx.stats().tile_fit_pct,
+             grid=np.array(sim.be.ctx.stats().grid_dim[:]), **st)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -198,6 +199,8 @@ def test_hip_ghost_path_at_scale_vs_single_context(tmp_path):
     order = np.argsort(gid)
     for p in parts:
         assert list(p["dts"]) == dts and p["ghosts"] > 1000
+        # a narrow x-slab is still evaluated from the LDS tile (the long axis of the slab is the middle one of the cell key)
+        assert p["tile_fit_pct"] >= 90, (p["tile_fit_pct"], p["grid"])
     for f in FIELDS:
         merged = np.concatenate([p[f] for p in parts])[order]
         assert rel_err(merged, ctx.field(f)) <= 1e-12, f
