@@ -101,12 +101,13 @@ __global__ __launch_bounds__(256) void pred_bbox_partial(const double *__restric
     }
 }
 
+// one wave per component (launched with 6 waves): lanes stride over the partials, then a wave reduction
 __global__ void pred_bbox_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= 6) return;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double r = k < 3 ? INFINITY : -INFINITY;
-    for (int b = 0; b < nb; b++) r = k < 3 ? fmin(r, part[(size_t)b * 6 + k]) : fmax(r, part[(size_t)b * 6 + k]);
-    out[k] = r;
+    for (int b = lane; b < nb; b += 64) r = k < 3 ? fmin(r, part[(size_t)b * 6 + k]) : fmax(r, part[(size_t)b * 6 + k]);
+    for (int o = 32; o > 0; o >>= 1) r = k < 3 ? fmin(r, __shfl_xor(r, o, 64)) : fmax(r, __shfl_xor(r, o, 64));
+    if (lane == 0) out[k] = r;
 }
 
 // sink accelerations = sum over ranks (rank order); optionally get_next_timestep's rule ([F]:851-859, t = t + dt of
@@ -212,7 +213,7 @@ hipError_t launch_pack_partials(sph_ctx *c, double *d_out) {
         pred_bbox_partial<<<dim3(nb), dim3(256), 0, c->stream>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->f[SPH_F_VX], c->f[SPH_F_VY],
                                                                  c->f[SPH_F_VZ], c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
                                                                  (int32_t)c->n_owned, c->n, c->d_dt, c->bbox_part);
-        pred_bbox_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->bbox_part, nb, d_out + 3 * MAX_SINKS + 1);
+        pred_bbox_final<<<dim3(1), dim3(384), 0, c->stream>>>(c->bbox_part, nb, d_out + 3 * MAX_SINKS + 1);
     } else {
         (void)hipMemsetAsync(d_out + 3 * MAX_SINKS + 1, 0xff, 6 * sizeof(double), c->stream);      // NaN: no prediction
     }

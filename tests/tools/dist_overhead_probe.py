@@ -17,3 +17,6 @@ sim = DistSim(HipBackend(0), gas, sinks, np.zeros(0))
 d = sim.run(2, 1e-2); sim.be.synchronize()
 t0 = time.perf_counter(); d = sim.run(10, d); sim.be.synchronize(); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("DistSim (P=1) ms/step", (t1 - t0) / 10 * 1e3, "final dt", d, dt)
+sim.profile = True
+d = sim.run(10, d); sim.be.synchronize()
+print("phases, ms/step (synchronised at phase boundaries):", {k: round(v / 10 * 1e3, 3) for k, v in sim.phase_s.items()})
