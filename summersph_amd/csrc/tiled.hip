@@ -131,8 +131,8 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                     const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const double r2 = dx * dx + dy * dy + dz * dz;
                     if (r2 <= rcut2 && j != (int)i) {
-                        const int q = cnt & 3;
-                        if (q == 0) buf.x = j; else if (q == 1) buf.y = j; else if (q == 2) buf.z = j; else buf.w = j;
+                        const int q = cnt & 3;              // selects, not branches: the accept path runs for every third candidate
+                        buf.x = q == 0 ? j : buf.x; buf.y = q == 1 ? j : buf.y; buf.z = q == 2 ? j : buf.z; buf.w = q == 3 ? j : buf.w;
                         if (q == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
                         cnt++;
                     }

@@ -17,4 +17,4 @@ for k in range(6):
     s = ctx.get_sinks()
     ok = all(np.all(np.isfinite(ctx.field(f))) for f in "x vx u alpha".split())
     print(f"step {50 * (k + 1):4d} n={ctx.n} dt={dt:.5f} t={t:.3f} E_kin+th={e:.6e} sink m={s['m'][0]:.8f} "
-          f"list max={st.nlist_max} cap={st.nlist_capacity} finite={ok}", flush=True)
+          f"list max={st.nlist_max} cap={st.nlist_capacity} tile_fit={st.tile_fit_pct}% finite={ok}", flush=True)
