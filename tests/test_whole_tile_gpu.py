@@ -40,6 +40,24 @@ def stirred_disc(n, seed=202):
     return gas, sinks
 
 
+def test_reference_fixtures_are_evaluated_by_the_whole_tile_kernels(capi):
+    """the disc fixtures of the real reference run through density_wt / forces_wt in the default context: the parity
+    statement of test_parity_gpu.py is about these kernels"""
+    from conftest import load_golden, rel_err
+    for name in ("disc3000_eval", "disc3000ns_eval"):
+        g = load_golden(name)
+        gas, sinks = ic.split_rows(g["ic"])
+        ctx = capi.Context(device=0)
+        ctx.upload(gas); ctx.set_sinks(sinks)
+        ctx.density(); ctx.forces()
+        assert ctx.stats().tile_fit_pct >= 90
+        for f in ("rho", "P", "c"):
+            assert rel_err(ctx.field(f), g[f]) <= 1e-13, (name, f)
+        for f in ("ax", "ay", "az", "du", "dalpha"):
+            assert rel_err(ctx.field(f), g["sph_" + f]) <= 1e-13, (name, f)
+        ctx.close()
+
+
 def test_thin_disc_runs_from_the_tile_and_matches_bitwise(capi):
     gas, sinks = stirred_disc(200_000)
     a, sa = evaluate(capi, gas, sinks, 0)
