@@ -173,16 +173,40 @@ def main():
     from summersph_amd import capi, ic
 
     dist = None
+    data_group, data_backend = None, args.backend
     if world > 1:
         import torch.distributed as dist
+        # control plane (barriers, the final max-reduction): gloo.  Data plane (halos, reductions of the run): RCCL over
+        # xGMI, one rank per GPU; if the RCCL group cannot be set up or fails its probe on ANY rank (an exception, e.g. two
+        # ranks given the same GPU), every rank falls back to host-staged gloo messages and the JSON line says so.
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # fewer GPUs than ranks: share (RCCL refuses, gloo runs)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo")
         if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="gloo")
-    red_dev = f"cuda:{local_rank}" if (world == 1 or args.backend == "nccl") else "cpu"
+            ok = 1
+            try:
+                dev = torch.device("cuda", local_rank)
+                data_group = dist.new_group(backend="nccl", device_id=dev)
+                probe = torch.full((8,), float(rank), dtype=torch.float64, device=dev)
+                dist.all_reduce(probe, group=data_group)
+                got = torch.empty((world, 2), dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(got.view(-1), torch.tensor([rank, world], dtype=torch.int64, device=dev), group=data_group)
+                nb = [q for q in (rank - 1, rank + 1) if 0 <= q < world]
+                rbuf = [torch.empty(4, dtype=torch.float64, device=dev) for _ in nb]
+                ops = [dist.P2POp(dist.isend, probe[:4].contiguous(), q, data_group) for q in nb] + \
+                      [dist.P2POp(dist.irecv, b, q, data_group) for q, b in zip(nb, rbuf)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize()
+                assert float(probe[0]) == world * (world - 1) / 2 and all(float(b[0]) == world * (world - 1) / 2 for b in rbuf)
+            except Exception as e:       # noqa: BLE001 -- whatever RCCL raises, the run continues on gloo
+                ok = 0
+                print(f"[bench rank {rank}] RCCL data plane unavailable ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                data_group, data_backend = None, "gloo"
+    red_dev = "cpu" if world > 1 else f"cuda:{local_rank}"
 
     if args.full_simulate:
         args.self_gravity = True
@@ -213,7 +237,7 @@ def main():
         del rows, gas
         be = HipBackend(local_rank, variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable else HipBackend(local_rank, flags=flags)
         # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
-        sim = DistSim(be, mine, sinks, bounds, group=None, comm_device=None if args.backend == "nccl" else "cpu")
+        sim = DistSim(be, mine, sinks, bounds, group=data_group, comm_device=None if data_backend == "nccl" else "cpu")
         ctx = be.ctx
 
         def barrier():
@@ -269,7 +293,8 @@ def main():
             "config": {"workload": wl, "mode": args.mode, "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean, "mean_wave_trips": st.nlist_wave_mean,
                        "max_neighbours": st.nlist_max, "grid": list(st.grid_dim), "reuse_density": bool(args.reuse_density),
                        "parallelism": "1 GPU" if world == 1 else
-                                      f"{world} x-slabs, ghost exchange + migration over RCCL (torch.distributed {args.backend})",
+                                      f"{world} x-slabs, ghost exchange + migration over "
+                                      + ("RCCL (torch.distributed nccl)" if data_backend == "nccl" else "host-staged gloo messages"),
                        "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
             "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else ("forces_wt" if st.tile_fit_pct >= 90 else "forces_kernel"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
