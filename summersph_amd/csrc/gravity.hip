@@ -332,6 +332,7 @@ __global__ __launch_bounds__(GB) void node_wave_records(int n, TreeArrays t, Roo
 // accepted the node sleeps until the walk leaves that subtree -- it wakes at the node's rope, which every exit
 // from the subtree reaches.  Each lane therefore accumulates exactly the contributions of its own walk, in the same
 // order as grav_walk (kept as the per-lane reference implementation, SPH_GRAV_WAVE=0).
+template <bool STATS>
 __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRec *__restrict__ rec, const double4 *__restrict__ leafA,
                                                      const double4 *__restrict__ drec, const int32_t *__restrict__ leaf_of,
                                                      const double *__restrict__ hvar,
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
             }
             const double f = (G * r.m) * W * (rs * rs * rs);              // [F]:281
             a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
-            sums++;
+            if (STATS) sums++;
         }
-        visits++;
-        if (stats && (threadIdx.x & 63) == 0) {          // debug histogram: visits by node size (levels below the root)
+        if (STATS) visits++;
+        if (STATS && (threadIdx.x & 63) == 0) {          // debug histogram: visits by node size (levels below the root)
             const double ratio = r.size2 > 0.0 ? r.size2 / (rb_size * rb_size) : 0.0;
             int lv = 0;
             while (lv < 15 && ratio > 0.0 && ratio < 1.0 / (double)(1ull << (2 * lv))) lv++;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
         }
     }
     if (live) { ax[i] = a0; ay[i] = a1; az[i] = a2; }
-    if (stats) {
+    if (STATS) {
         if ((threadIdx.x & 63) == 0) atomicAdd(&stats[0], (unsigned long long)visits);
         atomicAdd(&stats[1], (unsigned long long)sums);
     }
@@ -553,7 +554,8 @@ hipError_t launch_gravity(sph_ctx *c) {
             if (hipMalloc(reinterpret_cast<void **>(&stats), 18 * 8) != hipSuccess) return hipGetLastError();
             (void)hipMemsetAsync(stats, 0, 18 * 8, c->stream);
         }
-        grav_walk_wave<<<dim3((unsigned)((nt + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
+        auto walk = stats ? grav_walk_wave<true> : grav_walk_wave<false>;
+        walk<<<dim3((unsigned)((nt + GB - 1) / GB)), dim3(GB), 0, c->stream>>>(
             (int)nt, (int)n, reinterpret_cast<const WalkRec *>(c->g_wrec), ta.leafA, reinterpret_cast<const double4 *>(c->drec),
             ext ? nullptr : c->g_leaf_of, c->variable ? c->f[SPH_F_H] : nullptr, c->p.h, soft2,
             c->p.theta, c->p.G, c->grav_tab, c->p.nq, 2.0 / c->p.nq, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,
