@@ -111,3 +111,29 @@ def test_workgroups_that_do_not_fit_fall_back_inside_the_kernel(capi):
     assert 90 <= sa.tile_fit_pct < 100
     for f in FIELDS:
         assert np.array_equal(a[f], b[f]), f
+
+
+def test_counting_sort_gives_the_order_of_the_stable_radix_sort(tmp_path):
+    """grid.hip sorts by cell with a counting sort (histogram, scan, scatter, per-cell rank); SPH_SORT_RADIX=1 (read once per
+    process) restores rocprim's stable radix sort.  Same permutation, hence bitwise the same trajectory."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from summersph_amd import capi, ic\n"
+        "gas, sinks = ic.split_rows(ic.keplerian_disc(60_000, seed=17, nngb=85.0))\n"
+        "ctx = capi.Context(device=0)\n"
+        "ctx.upload(gas); ctx.set_sinks(sinks)\n"
+        "ctx.run(4, 1e-2, 0.0)\n"
+        "np.savez(sys.argv[1], **{f: ctx.field(f) for f in 'x y z vx vy vz u alpha'.split()})\n"
+    )
+    out = {}
+    for tag, env in (("count", {}), ("radix", {"SPH_SORT_RADIX": "1"})):
+        path = tmp_path / f"{tag}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env={**os.environ, **env}, timeout=300)
+        out[tag] = dict(np.load(path))
+    for f in out["count"]:
+        assert np.array_equal(out["count"][f], out["radix"][f]), f
