@@ -30,6 +30,17 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+// Neighbour-list rows read as whole int4 quads (whole-tile kernels) are read exactly once per pass: a streaming
+// (non-temporal) load keeps them from evicting the gather records, which ARE re-used, from L1 / L2 (forces_wt 0.485 ->
+// 0.454 ms on the bench disc).  NOT for the per-entry dword reads of the other kernels, which touch each 1-KB row in four
+// consecutive trips and lose their L1 hits with the hint (forces_kernel 0.535 -> 0.58 ms).
+__device__ __forceinline__ int4 load_row(const int4 *p) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int load_entry(const int32_t *p) { return *p; }
+
 // ---- fp64 reciprocal / square root helpers ---------------------------------------------------
 // A full IEEE fp64 division costs ~20 VALU instructions on CDNA4 and the reference's pair term has
 // nine of them.  The kernels use the hardware seed (v_rcp_f64 / v_rsq_f64) plus Newton / Goldschmidt

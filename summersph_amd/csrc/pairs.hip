@@ -147,15 +147,15 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
     // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
     // Lanes past their own count re-read their own record (a valid address) and are masked out.
-    int j1 = 0 < cnt ? mine[list_off<PACKED>(0)] : self;
-    int j2 = 1 < cnt ? mine[list_off<PACKED>(1)] : self;
+    int j1 = 0 < cnt ? load_entry(mine + list_off<PACKED>(0)) : self;
+    int j2 = 1 < cnt ? load_entry(mine + list_off<PACKED>(1)) : self;
     double4 p1 = drec[j1];
     double acc = 0.0;   // sum of m_j * w(q_ij), normalised once at the end
     for (int k = 0; k < kmax; k++) {
         const double4 pj = p1;
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = mine[list_off<PACKED>(k + 2)];
+        if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
         if (k + 1 < cnt) p1 = drec[j1];          // idle lanes issue no gather
         const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
         double dr, rs;
@@ -236,15 +236,15 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     // SPH sums, un-normalised: every term is linear in dW, so 1/(pi h^4) ([F]:126) is applied once at the end
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
 
-    int j1 = 0 < cnt ? mine[list_off<PACKED>(0)] : self;
-    int j2 = 1 < cnt ? mine[list_off<PACKED>(1)] : self;
+    int j1 = 0 < cnt ? load_entry(mine + list_off<PACKED>(0)) : self;
+    int j2 = 1 < cnt ? load_entry(mine + list_off<PACKED>(1)) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
         const double4 Aj = A1, Bj = B1, Cj = C1;
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = mine[list_off<PACKED>(k + 2)];
+        if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
         if (k + 1 < cnt) {                       // idle lanes issue no gather
             fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];

@@ -452,11 +452,11 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
         // list rows as int4 (four entries), fetched two rows ahead with wave-uniform, unconditional loads
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
         const int nrow = (kmax + 3) >> 2;
-        int4 qa = mine4[0];
-        int4 qb = mine4[(size_t)min(1, nrow - 1) * 64];
+        int4 qa = load_row(mine4);
+        int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
         double4 p1 = tile[0 < cnt ? tm.slot(qa.x) : 0];
         for (int r = 0; r < nrow; r++) {
-            const int4 qc = mine4[(size_t)min(r + 2, nrow - 1) * 64];
+            const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 4 * r + v;
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
         }
     } else if (!fits) {
         const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
-        int j1 = 0 < cnt ? mine[poff(0)] : self;
-        int j2 = 1 < cnt ? mine[poff(1)] : self;
+        int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
+        int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
         double4 p1 = drec[j1];
         for (int k = 0; k < kmax; k++) {
             const double4 pj = p1;
             j1 = j2;
-            if (k + 2 < cnt) j2 = mine[poff(k + 2)];
+            if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
             if (k + 1 < cnt) p1 = drec[j1];
             visit(pj, k < cnt);
         }
@@ -568,13 +568,13 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
     if (fits && kmax > 0) {
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
         const int nrow = (kmax + 3) >> 2;
-        int4 qa = mine4[0];
-        int4 qb = mine4[(size_t)min(1, nrow - 1) * 64];
+        int4 qa = load_row(mine4);
+        int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
         int jn = 0 < cnt ? qa.x : self;
         double4 A1 = tile[0 < cnt ? tm.slot(jn) : 0];
         double4 B1 = fg[(size_t)jn * 3 + 1], C1 = fg[(size_t)jn * 3 + 2];
         for (int r = 0; r < nrow; r++) {
-            const int4 qc = mine4[(size_t)min(r + 2, nrow - 1) * 64];
+            const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 4 * r + v;
@@ -590,14 +590,14 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
         }
     } else if (!fits) {
         const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
-        int j1 = 0 < cnt ? mine[poff(0)] : self;
-        int j2 = 1 < cnt ? mine[poff(1)] : self;
+        int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
+        int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
         const double4 *fj = fg + (size_t)j1 * 3;
         double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
         for (int k = 0; k < kmax; k++) {
             const double4 Aj = A1, Bj = B1, Cj = C1;
             j1 = j2;
-            if (k + 2 < cnt) j2 = mine[poff(k + 2)];
+            if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
             if (k + 1 < cnt) { fj = fg + (size_t)j1 * 3; A1 = fj[0]; B1 = fj[1]; C1 = fj[2]; }
             visit(Aj, Bj, Cj, k < cnt);
         }

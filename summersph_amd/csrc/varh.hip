@@ -364,15 +364,15 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
 
-    int e1 = 0 < cnt ? mine[voff(0)] : self;
-    int e2 = 1 < cnt ? mine[voff(1)] : self;
+    int e1 = 0 < cnt ? load_entry(mine + voff(0)) : self;
+    int e2 = 1 < cnt ? load_entry(mine + voff(1)) : self;
     double4 p1 = drec[e1 & IDX_MASK];
     double s1 = 0.0, s2 = 0.0;     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
     for (int k = 0; k < kmax; k++) {
         const double4 pj = p1;
         const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
         e1 = e2;
-        if (k + 2 < cnt) e2 = mine[voff(k + 2)];
+        if (k + 2 < cnt) e2 = load_entry(mine + voff(k + 2));
         if (k + 1 < cnt) p1 = drec[e1 & IDX_MASK];
         const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
         double dr, rs;
@@ -441,15 +441,15 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
 
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-    int e1 = 0 < cnt ? mine[voff(0)] : self;
-    int e2 = 1 < cnt ? mine[voff(1)] : self;
+    int e1 = 0 < cnt ? load_entry(mine + voff(0)) : self;
+    int e2 = 1 < cnt ? load_entry(mine + voff(1)) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
         const double4 Aj = A1, Bj = B1, Cj = C1;
         const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
         e1 = e2;
-        if (k + 2 < cnt) e2 = mine[voff(k + 2)];
+        if (k + 2 < cnt) e2 = load_entry(mine + voff(k + 2));
         if (k + 1 < cnt) {
             fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
