@@ -40,6 +40,7 @@ __device__ __forceinline__ int4 load_row(const int4 *p) {
     return make_int4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ int load_entry(const int32_t *p) { return *p; }
+__device__ __forceinline__ int comp4(const int4 &v, int u) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); }
 
 // ---- fp64 reciprocal / square root helpers ---------------------------------------------------
 // A full IEEE fp64 division costs ~20 VALU instructions on CDNA4 and the reference's pair term has

@@ -399,7 +399,6 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
 }
 
 __device__ __forceinline__ size_t poff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
-__device__ __forceinline__ int comp4(const int4 &v, int u) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); }
 
 template <int TCAP, int BS>
 __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const double4 *__restrict__ drec,

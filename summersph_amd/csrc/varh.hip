@@ -200,7 +200,6 @@ __device__ __forceinline__ double axis_gap2(double p, double lo, double e) {
 // reaches j's leaf; what update_h needs to know for a trial h)
 // layout: 4-packed, wave-strided (entry k of lane l in wave w = component k%4 of the int4 at
 // nlist4[(w*cap/4 + k/4)*64 + l]); the evaluation kernels read it in lockstep.
-__device__ __forceinline__ size_t voff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
 
 // Built from LDS-staged tiles.  For every offset o2 along the slowest grid axis
 // the candidates of a 256-particle workgroup lie in ONE contiguous interval of the sorted order (all
@@ -360,29 +359,44 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     const double4 pi = drec[self];
     const double hi = hh[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
-    const int kmax = wave_max[w];
-    const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
+    const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
+    const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
 
-    int e1 = 0 < cnt ? load_entry(mine + voff(0)) : self;
-    int e2 = 1 < cnt ? load_entry(mine + voff(1)) : self;
-    double4 p1 = drec[e1 & IDX_MASK];
+    // list rows as int4 (four entries), streamed two rows ahead with wave-uniform loads: a quarter of the list
+    // instructions of a per-entry read, and the rows do not displace the gather records from the caches
     double s1 = 0.0, s2 = 0.0;     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
-    for (int k = 0; k < kmax; k++) {
-        const double4 pj = p1;
-        const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
-        e1 = e2;
-        if (k + 2 < cnt) e2 = load_entry(mine + voff(k + 2));
-        if (k + 1 < cnt) p1 = drec[e1 & IDX_MASK];
-        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
-        double dr, rs;
-        fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
-        const double qi = dr * inv_h;
-        if (act && qi <= 2.0) {
-            double wl, dwl;
-            table_lerp2(lw, ldw, qi, inv_dq, pc.nq, wl, dwl);                            // [V]:486
-            s1 = fma(pj.w, wl, s1);                                                      // [V]:492
-            s2 = fma(pj.w, qi * dwl - 3.0 * wl, s2);                                     // [V]:487,493 (x -pi h^4)
+    if (kmax > 0) {
+        const int nrow = (kmax + 3) >> 2;
+        int4 qa = load_row(mine4);
+        int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
+        int e1 = 0 < cnt ? qa.x : self;
+        double4 p1 = drec[e1 & IDX_MASK];
+        for (int r = 0; r < nrow; r++) {
+            const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int k = 4 * r + v;
+                if (k < kmax) {                                     // wave-uniform
+                    const double4 pj = p1;
+                    const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
+                    if (k + 1 < cnt) {                              // idle lanes issue no gather
+                        e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
+                        p1 = drec[e1 & IDX_MASK];
+                    }
+                    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
+                    double dr, rs;
+                    fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
+                    const double qi = dr * inv_h;
+                    if (act && qi <= 2.0) {
+                        double wl, dwl;
+                        table_lerp2(lw, ldw, qi, inv_dq, pc.nq, wl, dwl);                            // [V]:486
+                        s1 = fma(pj.w, wl, s1);                                                      // [V]:492
+                        s2 = fma(pj.w, qi * dwl - 3.0 * wl, s2);                                     // [V]:487,493 (x -pi h^4)
+                    }
+                }
+            }
+            qa = qb; qb = qc;
         }
     }
     if (!live) return;
@@ -434,23 +448,28 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
     const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/(Om rho^2) c/2 alpha/2 h
     const int cnt = live ? min(ncount[i], cap) : 0;
-    const int kmax = wave_max[w];
-    const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
+    const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
+    const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
     const double hi = Cc.w;
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq, inv_pi = 1.0 / pc.kernel_pi;
     const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
 
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-    int e1 = 0 < cnt ? load_entry(mine + voff(0)) : self;
-    int e2 = 1 < cnt ? load_entry(mine + voff(1)) : self;
+    const int nrow = (kmax + 3) >> 2;
+    int4 qa = make_int4(0, 0, 0, 0), qb = qa;
+    if (kmax > 0) { qa = load_row(mine4); qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64); }
+    int e1 = 0 < cnt ? qa.x : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
+        if ((k & 3) == 0 && k > 0) {                // next row (wave-uniform): rows are streamed two ahead
+            qa = qb;
+            qb = load_row(mine4 + (size_t)min((k >> 2) + 1, nrow - 1) * 64);
+        }
         const double4 Aj = A1, Bj = B1, Cj = C1;
         const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
-        e1 = e2;
-        if (k + 2 < cnt) e2 = load_entry(mine + voff(k + 2));
-        if (k + 1 < cnt) {
+        if (k + 1 < cnt) {                          // idle lanes issue no gather
+            e1 = (k & 3) < 3 ? comp4(qa, (k & 3) + 1) : qb.x;
             fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
         }
@@ -552,19 +571,15 @@ __device__ void density_list(const double4 *__restrict__ drec, const int4 *__res
         r0 = r0 + pi.w * Wj;
         oa = oa + pi.w * W_h;
     }
-    for (int k = 0; k < cnt + tcnt; k++) {
-        const int kk = k < cnt ? k : k - cnt;
-        const int4 q = k < cnt ? mine[(size_t)(kk >> 2) * 64] : mine[(size_t)(cap4 - 1 - (kk >> 2)) * 64];
-        const int c4 = kk & 3;
-        const uint32_t ent = (uint32_t)(c4 == 0 ? q.x : c4 == 1 ? q.y : c4 == 2 ? q.z : q.w);
-        if (!(ent & FLAG_R)) continue;
+    auto visit = [&](uint32_t ent) {
+        if (!(ent & FLAG_R)) return;
         const double4 pj = drec[ent & IDX_MASK];
         const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
         const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-        if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) continue;
+        if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) return;
         const double dr = sqrt(r2);
         const double qi = dr / hn;
-        if (qi > 2.0) continue;
+        if (qi > 2.0) return;
         int kq = min((int)(qi / pc.dq), pc.nq - 1);
         const double a = (qi - kq * pc.dq) / pc.dq;
         const double Wj = ((1.0 - a) * w_tab[kq] + a * w_tab[kq + 1]) / n3;
@@ -572,6 +587,23 @@ __device__ void density_list(const double4 *__restrict__ drec, const int4 *__res
         const double W_h = -(dr * dWj - 3.0 * Wj) / hn;                               // [V]:487
         r0 = r0 + pj.w * Wj;
         oa = oa + pj.w * W_h;
+    };
+    // one 16-byte row = four entries; the D/F entries from the top of the column, the margin shell from its bottom
+    for (int row = 0; 4 * row < cnt; row++) {
+        const int4 q = mine[(size_t)row * 64];
+        const int left = cnt - 4 * row;
+        visit((uint32_t)q.x);
+        if (left > 1) visit((uint32_t)q.y);
+        if (left > 2) visit((uint32_t)q.z);
+        if (left > 3) visit((uint32_t)q.w);
+    }
+    for (int row = 0; 4 * row < tcnt; row++) {
+        const int4 q = mine[(size_t)(cap4 - 1 - row) * 64];
+        const int left = tcnt - 4 * row;
+        visit((uint32_t)q.x);
+        if (left > 1) visit((uint32_t)q.y);
+        if (left > 2) visit((uint32_t)q.z);
+        if (left > 3) visit((uint32_t)q.w);
     }
     rho = r0;
     om = 1.0 + (hn / (3.0 * r0)) * oa;                                                 // [V]:535
