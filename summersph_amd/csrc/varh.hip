@@ -186,7 +186,7 @@ __global__ __launch_bounds__(VBLOCK) void cell_hmax_kernel(const int32_t *__rest
 }
 
 __device__ __forceinline__ bool reaches(const double4 &leaf, double x, double y, double z) {
-    return fabs(x - leaf.x) < leaf.w && fabs(y - leaf.y) < leaf.w && fabs(z - leaf.z) < leaf.w;
+    return ((int)(fabs(x - leaf.x) < leaf.w) & (int)(fabs(y - leaf.y) < leaf.w) & (int)(fabs(z - leaf.z) < leaf.w)) != 0;     // no short circuit: no branches
 }
 
 // distance^2 from coordinate p to the cell interval [lo, lo+e] along one axis
@@ -291,19 +291,19 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                         if (r2 <= 4.0 * hm * hm * (1.0 + 1e-12) && j != (int)i) {
                             const double4 lj = tile_l[j - cb];
                             const bool rij = reaches(lj, pi.x, pi.y, pi.z);       // i's walk reaches j's leaf
-                            const bool inD = rij && r2 <= ri2;                    // [V]:479 + kernel support of h_i
+                            const bool inD = ((int)rij & (int)(r2 <= ri2)) != 0;     // [V]:479 + kernel support of h_i
                             const double hf = fmax(hi, pj.w);
-                            const bool inF = r2 <= 4.0 * hf * hf * (1.0 + 1e-12) &&
-                                             (oi > tile_o[j - cb] ? rij : reaches(li, pj.x, pj.y, pj.z));   // [V]:383
+                            const bool rji = reaches(li, pj.x, pj.y, pj.z);       // j's walk reaches i's leaf
+                            const bool inF = ((int)(r2 <= 4.0 * hf * hf * (1.0 + 1e-12)) & (int)(oi > tile_o[j - cb] ? rij : rji)) != 0;   // [V]:383
                             const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u) | (rij ? FLAG_R : 0u));
                             if (inD || inF) {
-                                const int q4 = cnt & 3;
-                                if (q4 == 0) buf.x = ent; else if (q4 == 1) buf.y = ent; else if (q4 == 2) buf.z = ent; else buf.w = ent;
+                                const int q4 = cnt & 3;             // selects, not branches
+                                buf.x = q4 == 0 ? ent : buf.x; buf.y = q4 == 1 ? ent : buf.y; buf.z = q4 == 2 ? ent : buf.z; buf.w = q4 == 3 ? ent : buf.w;
                                 if (q4 == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
                                 cnt++;
                             } else if (rij && r2 <= rim2) {                       // margin shell: only a trial h can need it
                                 const int q4 = tcnt & 3;
-                                if (q4 == 0) tbuf.x = ent; else if (q4 == 1) tbuf.y = ent; else if (q4 == 2) tbuf.z = ent; else tbuf.w = ent;
+                                tbuf.x = q4 == 0 ? ent : tbuf.x; tbuf.y = q4 == 1 ? ent : tbuf.y; tbuf.z = q4 == 2 ? ent : tbuf.z; tbuf.w = q4 == 3 ? ent : tbuf.w;
                                 if (q4 == 3 && tcnt < cap) mine[(size_t)(cap4 - 1 - (tcnt >> 2)) * 64] = tbuf;
                                 tcnt++;
                             }
