@@ -293,12 +293,20 @@ int one_step_device_dt(sph_ctx *c) {
     // SUMMER_SPH.f90:889-916
     API_TRY(do_density(c));
     API_TRY(do_forces(c));
-    API_TRY(do_kick(c, 0.0, true));
-    API_TRY(do_drift(c, 0.0, true));
+    {   // kick + drift, one pass over the state (bitwise what sph_kick + sph_drift give)
+        if (!c->rates_valid) { c->err = "sph_step: rates are stale"; return SPH_ERR_STATE; }
+        Timed t(c, SPH_K_KICK);
+        API_HIP(launch_kick_drift(c));
+        c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; c->order_valid = false;
+    }
     API_TRY(do_density(c));
     API_TRY(do_forces(c));
-    API_TRY(do_kick(c, 0.0, true));
-    { Timed t(c, SPH_K_DT); API_HIP(launch_next_dt(c, true)); }
+    {   // closing kick + get_next_timestep, one pass (bitwise what sph_kick + sph_next_dt give)
+        if (!c->rates_valid) { c->err = "sph_step: rates are stale"; return SPH_ERR_STATE; }
+        Timed t(c, SPH_K_DT);
+        API_HIP(launch_kick_next_dt(c, true));
+        c->eos_valid = false;
+    }
     if (c->variable) API_TRY(do_update_h(c));          // Variable.f90:1152
     if (c->variable && (c->p.flags & SPH_FLAG_SINK_CREATION)) {      // Variable.f90:1155, before accretion and bounds
         int32_t created = 0;

@@ -58,6 +58,32 @@ __global__ __launch_bounds__(EW_BLOCK) void drift_kernel(double *__restrict__ x,
     }
 }
 
+// kick immediately followed by drift (first half of a step, [F]:899-900): one pass instead of two; same expressions,
+// same results as kick_kernel + drift_kernel
+__global__ __launch_bounds__(EW_BLOCK) void kick_drift_kernel(KickArgs a, double *__restrict__ x, double *__restrict__ y,
+                                                              double *__restrict__ z, int64_t n, const double *__restrict__ dt_ptr,
+                                                              double *__restrict__ sink, int ns) {
+    const double dt = dt_ptr[0];
+    const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i < n) {
+        const double vx = a.vx[i] + 0.5 * a.ax[i] * dt, vy = a.vy[i] + 0.5 * a.ay[i] * dt, vz = a.vz[i] + 0.5 * a.az[i] * dt;
+        a.vx[i] = vx; a.vy[i] = vy; a.vz[i] = vz;
+        a.u[i] = a.u[i] + 0.5 * a.du[i] * dt;
+        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;
+        x[i] = x[i] + vx * dt;
+        y[i] = y[i] + vy * dt;
+        z[i] = z[i] + vz * dt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ns) {
+        const int s = threadIdx.x;
+        for (int k = 0; k < 3; k++) {
+            const double v = sink[(3 + k) * MAX_SINKS + s] + 0.5 * sink[(7 + k) * MAX_SINKS + s] * dt;
+            sink[(3 + k) * MAX_SINKS + s] = v;
+            sink[k * MAX_SINKS + s] = sink[k * MAX_SINKS + s] + v * dt;
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
@@ -90,6 +116,45 @@ __global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict_
     if (threadIdx.x == 0) {
         for (int k = 1; k < DT_BLOCK / WAVE; k++) mn = fmin(mn, sm[k]);
         part[blockIdx.x] = mn;
+    }
+}
+
+// the closing kick of a step immediately followed by get_next_timestep's per-particle part ([F]:910-911,845-850): one
+// pass; same expressions as kick_kernel + dt_partial (the minimum does not depend on the order)
+__global__ __launch_bounds__(DT_BLOCK) void kick_dt_kernel(KickArgs a, const double *__restrict__ cs, double h, int64_t n,
+                                                           const double *__restrict__ dt_ptr, double *__restrict__ sink, int ns,
+                                                           double *__restrict__ part, const int32_t *__restrict__ orig,
+                                                           int32_t n_owned, const double *__restrict__ hvar) {
+    __shared__ double sm[DT_BLOCK / WAVE];
+    const double dt = dt_ptr[0];
+    double mn = INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
+        const double ax = a.ax[i], ay = a.ay[i], az = a.az[i], du = a.du[i];
+        const double vx = a.vx[i] + 0.5 * ax * dt, vy = a.vy[i] + 0.5 * ay * dt, vz = a.vz[i] + 0.5 * az * dt;
+        const double u = a.u[i] + 0.5 * du * dt;
+        a.vx[i] = vx; a.vy[i] = vy; a.vz[i] = vz; a.u[i] = u;
+        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;
+        if (orig[i] >= n_owned) continue;                     // ghosts are timed by their owners
+        const double v2 = vx * vx + vy * vy + vz * vz;
+        const double a2 = ax * ax + ay * ay + az * az;
+        const double c1 = sqrt(v2 / a2);                      // [F]:846
+        const double c2 = u / fabs(du);                       // [F]:847
+        const double hi = hvar ? hvar[i] : h;
+        const double c3 = hi / sqrt(v2);                      // [F]:848
+        const double c4 = hi / (cs[i] + 1.2 * cs[i]);         // [F]:849
+        mn = fmin(fmin(fmin(mn, c1), fmin(c2, c3)), c4);
+    }
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < DT_BLOCK / WAVE; k++) mn = fmin(mn, sm[k]);
+        part[blockIdx.x] = mn;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ns) {                // [F]:753-755
+        const int s = threadIdx.x;
+        for (int k = 0; k < 3; k++)
+            sink[(3 + k) * MAX_SINKS + s] = sink[(3 + k) * MAX_SINKS + s] + 0.5 * sink[(7 + k) * MAX_SINKS + s] * dt;
     }
 }
 
@@ -139,11 +204,30 @@ hipError_t launch_kick(sph_ctx *c, double dt, bool dt_from_device) {
     return hipGetLastError();
 }
 
+hipError_t launch_kick_drift(sph_ctx *c) {
+    KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
+               c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]};
+    unsigned nb = (unsigned)std::max<int64_t>((c->n + EW_BLOCK - 1) / EW_BLOCK, 1);
+    kick_drift_kernel<<<dim3(nb), dim3(EW_BLOCK), 0, c->stream>>>(a, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->n, c->d_dt, c->sink, c->ns);
+    return hipGetLastError();
+}
+
 hipError_t launch_drift(sph_ctx *c, double dt, bool dt_from_device) {
     unsigned nb = (unsigned)std::max<int64_t>((c->n + EW_BLOCK - 1) / EW_BLOCK, 1);
     drift_kernel<<<dim3(nb), dim3(EW_BLOCK), 0, c->stream>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->f[SPH_F_VX],
                                                               c->f[SPH_F_VY], c->f[SPH_F_VZ], c->n, dt,
                                                               dt_from_device ? c->d_dt : nullptr, c->sink, c->ns);
+    return hipGetLastError();
+}
+
+hipError_t launch_kick_next_dt(sph_ctx *c, bool advance_t) {
+    KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
+               c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]};
+    int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
+    if (nb < 1) nb = 1;
+    kick_dt_kernel<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(a, c->f[SPH_F_C], c->p.h, c->n, c->d_dt, c->sink, c->ns, c->dt_part, c->orig,
+                                                               (int32_t)c->n_owned, c->variable ? c->f[SPH_F_H] : nullptr);
+    dt_final<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->p.dt_max, c->p.dt_min, advance_t ? 1 : 0, c->d_dt);
     return hipGetLastError();
 }
 
