@@ -182,7 +182,7 @@ __global__ __launch_bounds__(VBLOCK) void cell_hmax_kernel(const int32_t *__rest
     if (c >= ncells) return;
     double m = 0.0;
     for (int j = cell_start[c]; j < cell_start[c + 1]; j++) m = fmax(m, prec[j].w);
-    hmax[c] = m;
+    hmax[c] = 4.0 * m * m * (1.0 + 1e-12);          // stored as the squared reach (2 hmax)^2 (1 + 1e-12), what the build compares with
 }
 
 __device__ __forceinline__ bool reaches(const double4 &leaf, double x, double y, double z) {
@@ -263,7 +263,13 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
         for (int cb = lo; cb < hiv; cb += T_NV) {
             const int ce = min(cb + T_NV, hiv);
             __syncthreads();
-            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) { tile[t] = prec[cb + t]; tile_l[t] = lrec[cb + t]; tile_o[t] = number ? number[orig[cb + t]] : orig[cb + t]; }
+            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) {
+                // {x, y, z, (2 h_j)^2 (1 + 1e-12)}: every test below needs h_j only through this square, and x -> 4 x x c is
+                // monotone in floating point, so max(square_i, square_j) is bitwise the square of max(h_i, h_j)
+                double4 v = prec[cb + t];
+                v.w = 4.0 * v.w * v.w * (1.0 + 1e-12);
+                tile[t] = v; tile_l[t] = lrec[cb + t]; tile_o[t] = number ? number[orig[cb + t]] : orig[cb + t];
+            }
             __syncthreads();
             if (!use2) continue;
             // per-lane walk over this lane's own columns and cells (lanes of different columns advance in
@@ -281,20 +287,17 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                     js = jn;
                     if (jb >= je) continue;
                     const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
-                    const double rc = 2.0 * fmax(him, cell_hmax[row + c0]);
-                    if (gap > rc * rc * (1.0 + 1e-12)) continue;
+                    if (gap > fmax(rim2, cell_hmax[row + c0])) continue;     // (2 max(1.1 h_i, hmax_C))^2 (1 + 1e-12)
                     for (int j = jb; j < je; j++) {
                         const double4 pj = tile[j - cb];
                         const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                         const double r2 = dx * dx + dy * dy + dz * dz;
-                        const double hm = fmax(him, pj.w);
-                        if (r2 <= 4.0 * hm * hm * (1.0 + 1e-12) && j != (int)i) {
+                        if (r2 <= fmax(rim2, pj.w) && j != (int)i) {
                             const double4 lj = tile_l[j - cb];
                             const bool rij = reaches(lj, pi.x, pi.y, pi.z);       // i's walk reaches j's leaf
                             const bool inD = ((int)rij & (int)(r2 <= ri2)) != 0;     // [V]:479 + kernel support of h_i
-                            const double hf = fmax(hi, pj.w);
                             const bool rji = reaches(li, pj.x, pj.y, pj.z);       // j's walk reaches i's leaf
-                            const bool inF = ((int)(r2 <= 4.0 * hf * hf * (1.0 + 1e-12)) & (int)(oi > tile_o[j - cb] ? rij : rji)) != 0;   // [V]:383
+                            const bool inF = ((int)(r2 <= fmax(ri2, pj.w)) & (int)(oi > tile_o[j - cb] ? rij : rji)) != 0;   // [V]:383
                             const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u) | (rij ? FLAG_R : 0u));
                             if (inD || inF) {
                                 const int q4 = cnt & 3;             // selects, not branches
