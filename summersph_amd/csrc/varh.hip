@@ -383,9 +383,9 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
                 if (k < kmax) {                                     // wave-uniform
                     const double4 pj = p1;
                     const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
-                    if (k + 1 < cnt) {                              // idle lanes issue no gather
+                    if (k + 1 < cnt) {                              // idle lanes issue no gather, nor do entries that count for forces only
                         e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
-                        p1 = drec[e1 & IDX_MASK];
+                        if ((uint32_t)e1 & FLAG_D) p1 = drec[e1 & IDX_MASK];
                     }
                     const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
                     double dr, rs;
