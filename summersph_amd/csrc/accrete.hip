@@ -302,6 +302,20 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(hipGetLastError());
     for (int k = 0; k < 9; k++) std::swap(c->f[k], c->f_alt[k]);
     if (c->variable) std::swap(c->f[SPH_F_H], c->f_alt[9]);
+    // the reference's pack ([F]:481,554) keeps the survivors' density, pressure, accelerations and rates of the last
+    // evaluation: compact those too (one field at a time through the scratch array, whose mask use is over), so that a
+    // download after the last step of a run sees them
+    const bool keep_derived = c->rates_valid;
+    if (keep_derived) {
+        for (int k = SPH_F_RHO; k < SPH_F_COUNT; k++) {
+            if ((k == SPH_F_H) || (k == SPH_F_OMEGA && !c->variable)) continue;
+            CompactArgs cd{};
+            cd.src[0] = c->f[k]; cd.dst[0] = c->scratch; cd.nf = 1;
+            acc_compact<<<dim3(gb), dim3(AB), 0, c->stream>>>(cd, keep, pos, c->inv, n);
+            std::swap(c->f[k], c->scratch);
+        }
+        AC_CHECK(hipGetLastError());
+    }
     c->n = n_new; c->n_slots = n_new; c->dead_below = 0;
     c->n_owned = n_new;
     AC_CHECK(launch_iota(c, c->orig, n_new));
@@ -309,6 +323,7 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
     c->h_refresh_ok = false;
+    c->derived_kept = keep_derived;
     *removed = n - n_new;
     return SPH_OK;
 }

@@ -177,7 +177,7 @@ int do_density(sph_ctx *c) {
     if (!c->grid_valid) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
-        c->order_valid = true;
+        c->order_valid = true; c->derived_kept = false;
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         c->wave_class_valid = false; c->interior_done = false;
         if (c->variable) {
@@ -319,9 +319,23 @@ int one_step_device_dt(sph_ctx *c) {
     return SPH_OK;
 }
 
+// What an overwritten field invalidates -- shared by sph_upload_field*, sph_scatter_field_dev and sph_scatter_fields_dev.
+void field_written(sph_ctx *c, int field) {
+    if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) {
+        c->h_refresh_ok = field == SPH_F_H && (c->grid_valid || c->h_refresh_ok);     // only h is newer than the grid
+        c->grid_valid = false; c->rho_valid = false;
+    }
+    if (field <= SPH_F_Z) c->order_valid = false;
+    if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
+    c->derived_kept = false;
+}
+
 bool field_ready(const sph_ctx *c, int field) {
     if (field <= SPH_F_ALPHA) return true;
     if (field == SPH_F_H) return c->variable;
+    // accretion / cull compacted the derived arrays along with the state: the survivors keep the values of the last
+    // evaluation, as the reference's pack leaves them ([F]:481,554)
+    if (c->derived_kept) return field != SPH_F_OMEGA || c->variable;
     // derived arrays are in the current slot order as long as no re-sort happened since they were
     // written (a re-sort clears rates_valid)
     if (field == SPH_F_OMEGA) return c->variable && (c->rho_valid || c->rates_valid);
@@ -477,7 +491,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     resolve_timing(c);
     free_particle_arrays(c);
-    ctx_free(c, c->cell_start); ctx_free(c, c->cell_fill); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
+    ctx_free(c, c->cell_start); ctx_free(c, c->cell_fill); ctx_free(c, c->cell_hmax); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
     ctx_free(c, c->grav_tab); ctx_free(c, c->sink_radius);
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
@@ -520,6 +534,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     if (c->variable) API_HIP(launch_fill(c, c->f[SPH_F_H], c->p.h, n));    // until sph_upload_field(SPH_F_H) sets it
     API_HIP(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
+    c->derived_kept = false;
     return SPH_OK;
 }
 
@@ -660,12 +675,7 @@ static int upload_field_impl(sph_ctx *c, int field, const double *src, int64_t n
     const int f = field;
     API_HIP(launch_scatter_fields(c, 1, &f, 0, n, dsrc));
     API_HIP(hipStreamSynchronize(c->stream));
-    if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) {
-        c->h_refresh_ok = field == SPH_F_H && (c->grid_valid || c->h_refresh_ok);     // only h is newer than the grid
-        c->grid_valid = false; c->rho_valid = false;
-    }
-    if (field <= SPH_F_Z) c->order_valid = false;
-    if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
+    field_written(c, field);
     return SPH_OK;
 }
 
@@ -718,9 +728,8 @@ int sph_scatter_field_dev(sph_ctx *c, int field, int64_t first, int64_t count, c
         return SPH_ERR_ARG;
     DeviceGuard g(c->device);
     API_HIP(launch_scatter_field(c, c->f[field], first, count, d_vals));
-    if (field <= SPH_F_Z || field == SPH_F_M) { c->grid_valid = false; c->rho_valid = false; c->h_refresh_ok = false; }
-    if (field <= SPH_F_Z) c->order_valid = false;
-    if (field <= SPH_F_ALPHA || field == SPH_F_RHO) c->eos_valid = false;
+    if ((field == SPH_F_H || field == SPH_F_OMEGA) && !c->variable) { c->err = "field needs SPH_FLAG_VARIABLE_H"; return SPH_ERR_ARG; }
+    field_written(c, field);
     return SPH_OK;
 }
 
@@ -747,14 +756,7 @@ int sph_scatter_fields_dev(sph_ctx *c, int32_t nf, const int32_t *fields, int64_
     if (!fields_ok(c, nf, fields, false)) return SPH_ERR_ARG;
     DeviceGuard g(c->device);
     API_HIP(launch_scatter_fields(c, nf, fields, first, count, d_vals));
-    for (int f = 0; f < nf; f++) {
-        if (fields[f] <= SPH_F_Z || fields[f] == SPH_F_M || fields[f] == SPH_F_H) {
-            c->h_refresh_ok = fields[f] == SPH_F_H && (c->grid_valid || c->h_refresh_ok);
-            c->grid_valid = false; c->rho_valid = false;
-        }
-        if (fields[f] <= SPH_F_Z) c->order_valid = false;
-        if (fields[f] <= SPH_F_ALPHA || fields[f] == SPH_F_RHO || fields[f] == SPH_F_H || fields[f] == SPH_F_OMEGA) c->eos_valid = false;
-    }
+    for (int f = 0; f < nf; f++) field_written(c, fields[f]);
     return SPH_OK;
 }
 
@@ -831,7 +833,7 @@ int sph_selected_ids_dev(sph_ctx *c, int32_t box, int64_t count, int64_t *d_ids)
     if (!c || box < 0 || box >= c->sel_boxes || count != c->sel_counts[box] || (count > 0 && !d_ids)) return SPH_ERR_ARG;
     if (count == 0) return SPH_OK;
     DeviceGuard g(c->device);
-    API_HIP(hipMemcpyAsync(d_ids, c->sel_ids + (size_t)box * c->n_owned, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    API_HIP(hipMemcpyAsync(d_ids, c->sel_ids + (size_t)box * c->sel_stride, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
     if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
     return SPH_OK;
 }

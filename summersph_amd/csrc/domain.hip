@@ -146,6 +146,7 @@ __global__ void apply_partials(const double *__restrict__ all, int nranks, int s
 // ids (ascending original id) of the owned particles inside each of nbox boxes -> c->sel_ids + b * n_owned
 int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts) {
     const int64_t no = c->n_owned;
+    c->sel_stride = no;
     for (int b = 0; b < nbox; b++) counts[b] = 0;
     if (no == 0 || nbox == 0) return SPH_OK;
     const size_t need = (size_t)nbox * (size_t)no;

@@ -415,7 +415,7 @@ int grid_rebuild(sph_ctx *c) {
         if (ctx_alloc(c, &c->cell_fill, (size_t)c->cell_cap, "cell cursors") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
         if (c->variable) {
             ctx_free(c, c->cell_hmax);
-            if (ctx_alloc(c, &c->cell_hmax, (size_t)c->cell_cap, "cell hmax") != SPH_OK) return SPH_ERR_NOMEM;
+            if (ctx_alloc(c, &c->cell_hmax, (size_t)c->cell_cap, "cell hmax") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
         }
     }
 

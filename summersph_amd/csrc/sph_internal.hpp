@@ -72,6 +72,7 @@ struct sph_ctx {
     int64_t *sel_count = nullptr;
     void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;
     int32_t sel_boxes = 0; int64_t sel_counts[64] = {};  // last sph_select_boxes
+    int64_t sel_stride = 0;                              // ids of box b start at sel_ids + b * sel_stride (n_owned at select time)
     // split force evaluation (sph_forces_part): waves near the other GPUs' boxes wait for the ghost fields
     int32_t *wave_class = nullptr; double *bnd_boxes = nullptr; int32_t n_bnd_boxes = 0;
     bool wave_class_valid = false, interior_done = false;
@@ -167,6 +168,7 @@ struct sph_ctx {
     bool rho_valid = false;      // rho matches positions and masses
     bool eos_valid = false;      // P, c, frec match rho, u, alpha, v
     bool rates_valid = false;
+    bool derived_kept = false;   // after an accretion / cull: rho .. dalpha of the survivors, compacted with the state (downloads only)
 
     // statistics and timing
     int64_t grid_builds = 0, nlist_builds = 0, density_passes = 0, force_passes = 0;

@@ -18,6 +18,7 @@
 module sph_hip_host
   use, intrinsic :: iso_c_binding
   use sph_hip_binding
+  use sph_hip_textio
   implicit none
   private
   public :: dp, particle, sink, read_data_from_file, simulate, make_save
@@ -64,7 +65,8 @@ contains
     type(sink), allocatable, intent(inout) :: sinks(:)
     real(dp), allocatable :: rec(:, :), grown(:, :)
     character(len=1024) :: line
-    integer :: unit_no, ios, nrec, ngas, nsink, k, ig, is
+    integer :: unit_no, ios, nrec, ngas, nsink, k, ig, is, pos, nread, nlines, buffered
+    logical :: wrapped, at_line_end, more
     real(dp) :: v(8)
 
     open(newunit=unit_no, file=filename, status='old', action='read', iostat=ios)
@@ -75,14 +77,33 @@ contains
     read(unit_no, '(A)', iostat=ios) line          ! header
     allocate(rec(8, 4096))
     nrec = 0
+    pos = len(line) + 1                            ! nothing buffered yet
+    buffered = 0
     do
-      read(unit_no, '(A)', iostat=ios) line
-      if (ios /= 0) exit
-      if (len_trim(line) == 0) cycle
-      read(line, *, iostat=ios) v
+      ! A record is a run of values that may continue over line breaks, as for the reference's list-directed read
+      ! ([F]:647).  One record per line: the first eight values count, further columns are skipped.  A record wrapped
+      ! over several lines (a save written with list-directed output under flang: 80 columns per line) carries
+      ! 9 values for a gas particle (..., alpha) and 8 for a sink: when the 8th value ends a line, a following line
+      ! that holds a single value is the wrapped alpha of this record, not the start of the next one.
+      call next_values(unit_no, line, pos, v, nread, nlines, ios)
+      if (nread == 0) exit                         ! end of file between records
       if (ios /= 0) then
         write(*, *) 'Error reading line ', nrec + 1
         exit
+      end if
+      wrapped = nlines + buffered >= 2
+      at_line_end = tokens_left(line, pos) == 0
+      pos = len(line) + 1                          ! what is left of the line belongs to this record
+      buffered = 0
+      if (wrapped .and. at_line_end .and. v(7) /= 0.0_dp) then
+        call load_line(unit_no, line, pos, more)
+        if (more) then
+          if (tokens_left(line, 1) == 1) then
+            pos = len(line) + 1                    ! the wrapped alpha
+          else
+            buffered = 1                           ! first line of the next record
+          end if
+        end if
       end if
       if (nrec == size(rec, 2)) then
         allocate(grown(8, 2 * nrec))
@@ -250,7 +271,7 @@ contains
   ! The time loop.  Per step: density, forces, kick, drift, density, forces, kick, t += dt,
   ! next dt -- one sph_step call.  Saves every end_time/1000 of simulated time.
   ! ------------------------------------------------------------------------------------------
-  subroutine simulate(bodies, sinks, end_time_in, max_steps, quiet, device, dt_log, sph_only)
+  subroutine simulate(bodies, sinks, end_time_in, max_steps, quiet, device, dt_log, sph_only, saves)
     type(particle), allocatable, intent(inout) :: bodies(:)
     type(sink), intent(inout) :: sinks(:)
     real(dp), intent(in), optional :: end_time_in
@@ -258,14 +279,15 @@ contains
     logical, intent(in), optional :: quiet
     real(dp), allocatable, intent(out), optional :: dt_log(:)
     logical, intent(in), optional :: sph_only     ! .true.: leave out self-gravity, accretion and the cull
+    logical, intent(in), optional :: saves        ! periodic saveN.txt files on / off (default: on unless max_steps is given)
 
     type(c_ptr) :: ctx
     type(sph_params) :: prm
     real(c_double) :: t, dt
-    real(dp) :: end_time, next_save, save_every
+    real(dp) :: end_time, next_save
     real(dp), allocatable :: dts(:)
     integer :: step, save_no, step_limit, dev, i
-    logical :: talk
+    logical :: talk, do_saves
 
     end_time = 1000.0_dp
     if (present(end_time_in)) end_time = end_time_in
@@ -275,6 +297,8 @@ contains
     if (present(quiet)) talk = .not. quiet
     dev = 0
     if (present(device)) dev = device
+    do_saves = .not. present(max_steps)          ! a step-limited (test) run writes no saveN.txt unless asked to
+    if (present(saves)) do_saves = saves
 
     call check(c_null_ptr, sph_params_default(prm), 'sph_params_default')
     prm%h = smoothing
@@ -289,7 +313,6 @@ contains
 
     t = 0.0_c_double
     dt = 1.0e-2_c_double
-    save_every = end_time / 1000.0_dp
     next_save = 0.0_dp      ! the reference writes save0 on its first iteration
     save_no = 0
     step = 0
@@ -297,11 +320,15 @@ contains
     dts(0) = dt
 
     do while (t < end_time .and. step < step_limit)
-      if (t >= next_save .and. .not. present(max_steps)) then
-        call pull_state(ctx, bodies, sinks, .false.)
-        call make_save(bodies, sinks, save_no)
-        save_no = save_no + 1
-        next_save = save_no * save_every
+      ! save check: the reference compares t > t_list(t_test) with t_list(i) = i*end_time/1000 and t_test starting at 0
+      ! (out of bounds: observed to write save0 on the first iteration); one save per iteration at most
+      if (do_saves) then
+        if (save_no == 0 .or. t > next_save) then
+          call pull_state(ctx, bodies, sinks, .false.)
+          call make_save(bodies, sinks, save_no)
+          save_no = save_no + 1
+          next_save = (save_no * end_time) / 1000
+        end if
       end if
       if (talk) print *, 'SPH Particles:', size(bodies), 'dt :', dt, 'time : ', t
 

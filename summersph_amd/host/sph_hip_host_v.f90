@@ -13,6 +13,7 @@
 module sph_hip_host_v
   use, intrinsic :: iso_c_binding
   use sph_hip_binding
+  use sph_hip_textio
   implicit none
   private
   public :: dp, particle, sink, param, read_data_from_file, read_params_from_file, default_params, simulate, make_save
@@ -114,7 +115,7 @@ contains
     type(sink), allocatable, intent(inout) :: sinks(:)
     real(dp), allocatable :: rec(:, :), grown(:, :)
     character(len=1024) :: line
-    integer :: unit_no, ios, nrec, ngas, nsink, k, ig, is
+    integer :: unit_no, ios, nrec, ngas, nsink, k, ig, is, pos, nread, nlines
     real(dp) :: v(10)
 
     open(newunit=unit_no, file=filename, status='old', action='read', iostat=ios)
@@ -125,20 +126,21 @@ contains
     read(unit_no, '(A)', iostat=ios) line          ! header
     allocate(rec(10, 4096))
     nrec = 0
+    pos = len(line) + 1                            ! nothing buffered yet
     do
-      read(unit_no, '(A)', iostat=ios) line
-      if (ios /= 0) exit
-      if (len_trim(line) == 0) cycle
+      ! A record is a run of values that may continue over line breaks, as for the reference's list-directed
+      ! read ([V]:782; flang wraps list-directed saves at 80 columns): 8 values, and for gas rows (energy /= 0) two more
+      ! (alpha, smoothing length); what is left of the record's last line is skipped.  Sink rows carry 8 values
+      ! ([V]:938), which the reference's own 10-value read would mis-parse.
       v = 0.0_dp
-      read(line, *, iostat=ios) v                  ! gas rows carry 10 values ...
-      if (ios /= 0) then
-        read(line, *, iostat=ios) v(1:8)           ! ... the sink rows the reference writes carry 8
-        v(9:10) = 0.0_dp
-      end if
+      call next_values(unit_no, line, pos, v(1:8), nread, nlines, ios)
+      if (nread == 0) exit                         ! end of file between records
+      if (ios == 0 .and. v(7) /= 0.0_dp) call next_values(unit_no, line, pos, v(9:10), nread, nlines, ios)
       if (ios /= 0) then
         write(*, *) 'Error reading line ', nrec + 1
         exit
       end if
+      pos = len(line) + 1                          ! rest of the line belongs to this record
       if (nrec == size(rec, 2)) then
         allocate(grown(10, 2 * nrec))
         grown(:, 1:nrec) = rec
@@ -299,7 +301,7 @@ contains
 
   ! The time loop, Variable.f90:1085-1165: per step one sph_step call (density, forces, kick, drift, density,
   ! forces, kick, t += dt, next dt, calc_smoothing, accretion, bounds).  Saves every end_time/1000.
-  subroutine simulate(bodies, sinks, params, max_steps, quiet, device, dt_log, sph_only)
+  subroutine simulate(bodies, sinks, params, max_steps, quiet, device, dt_log, sph_only, saves)
     type(particle), allocatable, intent(inout) :: bodies(:)
     type(sink), allocatable, intent(inout) :: sinks(:)
     type(param), intent(in) :: params
@@ -307,14 +309,15 @@ contains
     logical, intent(in), optional :: quiet
     real(dp), allocatable, intent(out), optional :: dt_log(:)
     logical, intent(in), optional :: sph_only     ! .true.: leave out self-gravity, accretion and the cull
+    logical, intent(in), optional :: saves        ! periodic saveN.txt files on / off (default: on unless max_steps is given)
 
     type(c_ptr) :: ctx
     type(sph_params) :: prm
     real(c_double) :: t, dt
-    real(dp) :: next_save, save_every
+    real(dp) :: next_save
     real(dp), allocatable :: dts(:)
     integer :: step, save_no, step_limit, dev, i
-    logical :: talk
+    logical :: talk, do_saves
 
     step_limit = huge(1)
     if (present(max_steps)) step_limit = max_steps
@@ -322,6 +325,8 @@ contains
     if (present(quiet)) talk = .not. quiet
     dev = 0
     if (present(device)) dev = device
+    do_saves = .not. present(max_steps)          ! a step-limited (test) run writes no saveN.txt unless asked to
+    if (present(saves)) do_saves = saves
 
     call check(c_null_ptr, sph_params_default_variable(prm), 'sph_params_default_variable')
     prm%flags = ior(ior(SPH_FLAG_VARIABLE_H, SPH_FLAG_SINK_CREATION), ior(SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL))
@@ -341,7 +346,6 @@ contains
 
     t = 0.0_c_double
     dt = 1.0e-2_c_double
-    save_every = params%end_time / 1000.0_dp
     next_save = 0.0_dp
     save_no = 0
     step = 0
@@ -349,11 +353,15 @@ contains
     dts(0) = dt
 
     do while (t < params%end_time .and. step < step_limit)
-      if (t >= next_save .and. .not. present(max_steps)) then
-        call pull_state(ctx, bodies, sinks, .false.)
-        call make_save(bodies, sinks, save_no)
-        save_no = save_no + 1
-        next_save = save_no * save_every
+      ! save check: the reference compares t > t_list(t_test) with t_list(i) = i*end_time/1000 and t_test starting at 0
+      ! (out of bounds: observed to write save0 on the first iteration); one save per iteration at most
+      if (do_saves) then
+        if (save_no == 0 .or. t > next_save) then
+          call pull_state(ctx, bodies, sinks, .false.)
+          call make_save(bodies, sinks, save_no)
+          save_no = save_no + 1
+          next_save = (save_no * params%end_time) / 1000
+        end if
       end if
       if (talk) print *, 'SPH Particles:', size(bodies), 'dt :', dt, 'time : ', t
 

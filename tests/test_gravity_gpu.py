@@ -86,6 +86,10 @@ def test_accretion_and_cull_vs_reference_fixture(capi):
             assert rel_err(ctx.field(f), g[p + f]) <= 1e-11, (k, f)
         s = ctx.get_sinks()
         assert abs(s["m"][0] - g[p + "sm"][0]) <= 1e-15 and abs(s["x"][0] - g[p + "sx"][0]) <= 1e-12
+        # the survivors keep density, accelerations and rates of the step's last evaluation, as the reference's pack
+        # leaves them -- also right after a step that removed particles (step 1: 2000 -> 1996)
+        for f in "rho ax ay az du dalpha".split():
+            assert rel_err(ctx.field(f), g[p + f]) <= 1e-11, (k, f)
     assert ns == [int(v) for v in g["full_n_seq"]] and ns[1] == ns[0] - 4
     assert dts == list(g["full_dt_seq"])
     ctx.close()

@@ -28,7 +28,8 @@ def test_host_builds_with_amdflang():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,variant,nsteps", [("sod1000_traj", "sph", 5), ("disc3000_traj", "sph", 5),
-                                                 ("disc3000_traj", "full", 5), ("acc2000_traj", "full", 3)])
+                                                 ("disc3000_traj", "full", 5), ("acc2000_traj", "full", 3),
+                                                 ("acc2000_traj", "full", 1)])      # the LAST step removes particles
 def test_fortran_host_trajectory(tmp_path, name, variant, nsteps):
     """variant 'full' = the host's default: simulate() as the reference runs it (gas self-gravity, accretion,
     boundary cull); 'sph' leaves those three out"""
@@ -120,3 +121,32 @@ def test_fortran_host_variable_h_sink_creation(tmp_path):
     assert np.max(np.abs(sinks[:, 0] - g["full_s3_sx"])) <= 1e-9
     for col, f in enumerate("x y z vx vy vz u m alpha h".split()):
         assert rel_err(gas[:, col], g["full_s3_" + f]) <= 1e-9, f
+
+
+@pytest.mark.gpu
+def test_fortran_host_periodic_saves(tmp_path):
+    """the save cadence of simulate(): save0 on the first iteration, then one save per iteration once
+    t > k * end_time / 1000 (SUMMER_SPH.f90:881-884); the saves hold the state at the START of their iteration"""
+    g = load_golden("disc3000_traj")
+    icf = tmp_path / "ic.txt"
+    txtio.write_ic(str(icf), g["ic"])
+    snap = tmp_path / "final.txt"
+    # end time 0.04: dt = 0.01, 0.015, 0.0225 -> t = 0, 0.01, 0.025, 0.0475: three iterations, three saves
+    r = subprocess.run([_build(), str(icf), "100", str(snap), "sph", "saves", "tend=0.04"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dts = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("dt ")]
+    assert dts == list(g["sph_dt_seq"])[:4]
+    saves = sorted(p.name for p in tmp_path.glob("save*.txt"))
+    assert saves == ["save0.txt", "save1.txt", "save2.txt"]
+    gas0, sinks0 = txtio.read_snapshot(str(tmp_path / "save0.txt"))
+    ic_gas = g["ic"][g["ic"][:, 6] != 0.0]
+    assert np.array_equal(gas0[:, :8], ic_gas) and sinks0.shape[0] == 1
+    gas1, _ = txtio.read_snapshot(str(tmp_path / "save1.txt"))
+    assert rel_err(gas1[:, 0], g["sph_s1_x"]) <= 1e-12 and rel_err(gas1[:, 6], g["sph_s1_u"]) <= 1e-12
+    # a save is a valid input again (alpha restarts at 0 as in the reference)
+    back = tmp_path / "back.txt"
+    r = subprocess.run([_build(), str(tmp_path / "save2.txt"), "-1", str(back)], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gas2, _ = txtio.read_snapshot(str(tmp_path / "save2.txt"))
+    gasb, _ = txtio.read_snapshot(str(back))
+    assert np.array_equal(gas2[:, :8], gasb[:, :8])
