@@ -150,7 +150,6 @@ def main():
     ap.add_argument("--no-variable", action="store_true", help="skip the extra variable-h measurement at N = 1")
     ap.add_argument("--reuse-density", action="store_true", help="SPH_FLAG_REUSE_DENSITY (NOT the headline mode)")
     ap.add_argument("--no-tiles", action="store_true", help="SPH_FLAG_NO_LDS_TILES: per-lane-gather list build (A/B)")
-    ap.add_argument("--tile-eval", action="store_true", help="SPH_FLAG_LDS_TILE_EVAL: LDS-staged density/forces (A/B)")
     ap.add_argument("--mode", default="fixed", choices=["fixed", "variable"],
                     help="headline workload: [F] fixed h (default) or [V] per-particle h")
     ap.add_argument("--ic", default="disc", choices=["disc", "ring"], help="fixed-h workload: the uniform disc (headline) or "
@@ -212,7 +211,7 @@ def main():
         args.self_gravity = True
     variable = args.mode == "variable"
     flags = (capi.FLAG_REUSE_DENSITY if args.reuse_density else 0) | (capi.FLAG_NO_LDS_TILES if args.no_tiles else 0) \
-        | (capi.FLAG_LDS_TILE_EVAL if args.tile_eval else 0) | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0) \
+        | (capi.FLAG_SELF_GRAVITY if args.self_gravity else 0) \
         | (capi.FLAG_ACCRETE_CULL if args.full_simulate else 0) \
         | (capi.FLAG_SINK_CREATION if args.full_simulate and args.mode == "variable" else 0)
 

@@ -85,9 +85,8 @@ typedef struct sph_params {
                                     number of sinks may grow by one per step (sph_sink_count)                  */
 #define SPH_FLAG_NO_LDS_TILES 4  /* fixed-h path: build the neighbour list with per-lane gathers (pairs.hip)
                                    instead of LDS-staged tiles (tiled.hip); A/B measurements        */
-#define SPH_FLAG_LDS_TILE_EVAL 8 /* fixed-h path: also run density/forces from LDS-staged tiles.  Same
-                                   results up to summation order; measured SLOWER than the default
-                                   direct gathers on MI355X, kept for tuning  */
+/* flag bit 8 (round 1: SPH_FLAG_LDS_TILE_EVAL, chunk-staged density/forces kernels) was measured slower in every
+   configuration and is gone; the bit is ignored */
 #define SPH_FLAG_NO_WHOLE_TILE 128 /* fixed-h path: density/forces with the memory gathers of pairs.hip only, never the
                                    whole-tile kernels of tiled.hip (bitwise the same results); A/B measurements */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
@@ -130,6 +129,8 @@ typedef struct sph_stats {
     int64_t grid_builds, nlist_builds, density_passes, force_passes;
     int64_t device_bytes;   /* HBM held by the context                                    */
     double  nlist_wave_mean;/* mean over wavefronts of the longest list in the wave = trips the pair kernels run */
+    int32_t tile_fit_pct_forces; /* as tile_fit_pct, for the forces kernel's workgroup size and tile record            */
+    int32_t reserved0;
 } sph_stats;
 
 /* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation

@@ -20,7 +20,6 @@ KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt
 FLAG_REUSE_DENSITY = 1
 FLAG_VARIABLE_H = 2
 FLAG_NO_LDS_TILES = 4
-FLAG_LDS_TILE_EVAL = 8
 FLAG_SELF_GRAVITY = 16
 FLAG_ACCRETE_CULL = 32
 FLAG_SINK_CREATION = 64
@@ -57,7 +56,8 @@ class Stats(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_cells", C.c_int64), ("grid_dim", C.c_int32 * 3),
                 ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("tile_fit_pct", C.c_int32), ("nlist_mean", C.c_double),
                 ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
-                ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double)]
+                ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double),
+                ("tile_fit_pct_forces", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class SphError(RuntimeError):

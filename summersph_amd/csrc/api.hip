@@ -43,6 +43,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class); ctx_free(c, c->leaf_half);
+    ctx_free(c, c->plan_d); ctx_free(c, c->plan_f); ctx_free(c, c->deal);
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
@@ -78,6 +79,9 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     API_TRY(ctx_alloc(c, &c->ncount, (size_t)cap, "neighbour counts"));
     API_TRY(ctx_alloc(c, &c->wave_max, (size_t)c->nl_waves_cap, "wave max"));
     API_TRY(ctx_alloc(c, &c->wave_class, (size_t)c->nl_waves_cap, "wave classes"));
+    API_TRY(ctx_alloc(c, &c->plan_d, (size_t)(cap / 256 + 2) * 8, "tile plans (density)"));
+    API_TRY(ctx_alloc(c, &c->plan_f, (size_t)(cap / 256 + 2) * 8, "tile plans (forces)"));
+    API_TRY(ctx_alloc(c, &c->deal, 2 * ((size_t)cap + 256), "dealing order"));
     if (c->variable) {
         API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));
         API_TRY(ctx_alloc(c, &c->lrec, (size_t)cap * 4, "leaf boxes"));
@@ -195,8 +199,7 @@ int do_density(sph_ctx *c) {
     if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
         API_HIP(c->variable ? launch_eos_only_v(c, pc) : launch_eos_only(c, pc));
     } else {
-        API_HIP(c->variable ? launch_density_v(c, pc) : (c->tiled_eval ? launch_density_tiled(c, pc)
-                                                                   : ((c->whole_tile && c->wt_ok) ? launch_density_wt(c, pc) : launch_density(c, pc))));
+        API_HIP(c->variable ? launch_density_v(c, pc) : ((c->whole_tile && c->wt_ok) ? launch_density_wt(c, pc) : launch_density(c, pc)));
         c->density_passes++;
     }
     c->rho_valid = true; c->eos_valid = true;
@@ -212,8 +215,7 @@ int do_forces(sph_ctx *c) {
         API_HIP(launch_gravity(c));
     }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (c->tiled_eval ? launch_forces_tiled(c, pc)
-                                                                   : ((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc)))); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : ((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc))); }
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -222,19 +224,19 @@ int do_forces(sph_ctx *c) {
 // forces in two parts (multi-GPU overlap): 1 = sink gravity + the waves that cannot see a ghost, while the ghost
 // fields are still travelling; 2 = the remaining waves, after sph_refresh_eos
 int do_forces_part(sph_ctx *c, int part) {
-    if (c->variable || c->gravity || c->tiled_eval) { c->err = "sph_forces_part: fixed-h contexts without self-gravity only"; return SPH_ERR_STATE; }
+    if (c->variable || c->gravity) { c->err = "sph_forces_part: fixed-h contexts without self-gravity only"; return SPH_ERR_STATE; }
     if (!c->eos_valid || !c->grid_valid) { c->err = "sph_forces_part: call sph_density first"; return SPH_ERR_STATE; }
     const PairConst pc = make_pair_const(c);
     if (part == 1) {
         if (!c->wave_class_valid) { API_HIP(launch_classify_waves(c)); c->wave_class_valid = true; }
         { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-        { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 1) : launch_forces(c, pc, 1)); }
+        { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 1) : launch_forces(c, pc, 1)); }
         c->interior_done = true;
         c->rates_valid = false;
         return SPH_OK;
     }
     if (!c->interior_done) { c->err = "sph_forces_part: part 2 before part 1"; return SPH_ERR_STATE; }
-    { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok) ? launch_forces_wt(c, pc, 2) : launch_forces(c, pc, 2)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 2) : launch_forces(c, pc, 2)); }
     c->interior_done = false;
     c->force_passes++;
     c->rates_valid = true;
@@ -439,13 +441,13 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     c->variable = (p->flags & SPH_FLAG_VARIABLE_H) != 0;
     c->gravity = (p->flags & SPH_FLAG_SELF_GRAVITY) != 0;
     c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
-    c->tiled_eval = c->tiled && (p->flags & SPH_FLAG_LDS_TILE_EVAL) != 0;
     // whole-tile kernels: 116 KB tile + the kernel table must fit the 160 KB of LDS (nq <= ~5500)
-    c->whole_tile = c->tiled && !c->tiled_eval && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0 &&
+    c->whole_tile = c->tiled && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0 &&
                     (size_t)((p->nq + 2) & ~1) * sizeof(double) + (size_t)WT_TILE_RECORDS * 32 + 1024 <= (size_t)160 * 1024;
     c->packed_list = c->tiled;
     c->device = device;
     DeviceGuard g(device);
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
     int st = SPH_OK;
     auto fail = [&](int s) { sph_ctx_destroy(c); return s; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
@@ -639,6 +641,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
     for (int a = 0; a < 3; a++) o->grid_dim[a] = c->grid.dim[a];
     o->nlist_capacity = c->nl_cap; o->nlist_max = c->nl_max;
     o->tile_fit_pct = c->whole_tile ? c->wt_fit_pct : -1;
+    o->tile_fit_pct_forces = c->whole_tile ? c->wt_fit_pct_f : -1;
     o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
     o->density_passes = c->density_passes; o->force_passes = c->force_passes;
     o->device_bytes = c->device_bytes;

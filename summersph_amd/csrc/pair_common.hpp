@@ -74,11 +74,15 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &s, double &rs)
 // lookup_kernel's interpolation (SUMMER_SPH.f90:114-118), table in LDS or global; returns the
 // un-normalised value.  k = min(int(q/dq), nq-1), a = (q - k dq)/dq are evaluated as q*(1/dq):
 // identical except within an ulp of a table knot, where the (continuous) interpolant changes by O(1e-16).
+// (The pair terms are written with explicit fma() under contract(off): which products the compiler fuses would otherwise
+// depend on the kernel a term is inlined into, and the kernel sets -- pairs.hip, the tile variants of tiled.hip -- could
+// not be compared bitwise.)
 __device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double inv_dq, int nq) {
+#pragma clang fp contract(off)
     const double t = qi * inv_dq;
     const int k = min((int)t, nq - 1);
     const double a = t - (double)k;
-    return (1.0 - a) * tab[k] + a * tab[k + 1];
+    return fma(a, tab[k + 1], (1.0 - a) * tab[k]);
 }
 
 // both tables at once (same knot, same weight)
@@ -89,6 +93,166 @@ __device__ __forceinline__ void table_lerp2(const double *__restrict__ tw, const
     const double a = t - (double)k, b = 1.0 - a;
     w = b * tw[k] + a * tw[k + 1];
     dw = b * tdw[k] + a * tdw[k + 1];
+}
+
+// ---- the pair terms, written ONCE (pairs.hip, tiled.hip and varh.hip all call these) -----------------------------------
+
+// force gather record (FREC doubles): A = x y z m | B = vx vy vz rho/2 | C = c/2  alpha/2  P/rho^2  h
+// (halved values: 0.5*(a_i + a_j) == a_i/2 + a_j/2 exactly, which saves three multiplies per pair; variable h stores
+// P/(Omega rho^2) in C.z, Variable.f90:413, and its h in C.w)
+__device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i, const double4 &pm, double vx, double vy,
+                                           double vz, double rho, double P_over_rho2, double c, double alpha, double h) {
+    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
+    fr[0] = pm;
+    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
+    fr[2] = make_double4(0.5 * c, 0.5 * alpha, P_over_rho2, h);
+}
+
+// one visit of the density sum, [F]:443-455: acc += m_j w(q_ij) (un-normalised, [F]:125 is applied once at the end)
+__device__ __forceinline__ void density_visit(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lds_w,
+                                              double inv_h, double inv_dq, int nq, double &acc) {
+#pragma clang fp contract(off)
+    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
+    double dr, rs;
+    fast_sqrt_rsqrt(fma(n2, n2, fma(n1, n1, n0 * n0)), dr, rs);             // [F]:446
+    const double qi = dr * inv_h;                                          // [F]:111
+    if (act && qi <= 2.0)                                                  // [F]:113
+        acc = fma(pj.w, table_lerp(lds_w, qi, inv_dq, nq), acc);           // [F]:114-118,454
+}
+
+// self term, normalisation, EOS and the force record of particle i ([F]:443-455 visits the particle's own leaf: r = 0;
+// [F]:125; get_pressure_and_sound_speed [F]:465-466)
+__device__ __forceinline__ void density_epilogue(const PairConst &pc, int64_t i, const double4 &pi, double acc, double w0,
+                                                 const double *__restrict__ u, const double *__restrict__ alpha,
+                                                 const double *__restrict__ vx, const double *__restrict__ vy,
+                                                 const double *__restrict__ vz, double *__restrict__ rho,
+                                                 double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec) {
+    acc = fma(pi.w, w0, acc);
+    const double rhoi = acc / pc.wnorm;
+    const double Pi = pc.gamma_m1 * u[i] * rhoi;
+    const double ci = sqrt(pc.gamma * Pi / rhoi);
+    rho[i] = rhoi; P[i] = Pi; cs[i] = ci;
+    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi / (rhoi * rhoi), ci, alpha[i], pc.h);   // [F]:381: P/(rho*rho)
+}
+
+// SPH sums of one target, un-normalised: every term is linear in dW, so 1/(pi h^4) ([F]:126) is applied once at the end
+struct ForceSums { double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0; };
+
+// a neighbour as the force pair term needs it
+struct Nbr { double x, y, z, m, vx, vy, vz, rho_h, c_h, al_h, P_r2; };
+
+__device__ __forceinline__ Nbr nbr_of(const double4 &A, const double4 &B, const double4 &C) {
+    return Nbr{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z};
+}
+
+// one visit of the fixed-h force sums, gather form of [F]:356-391.  A, B, C: the target's record; dw_of(q): the
+// interpolated, un-normalised dw table value.  Beyond 2h every term is exactly 0; r == 0 (coincident points): DESIGN.md.
+// masked flavour: the same operations for every lane, without control flow -- a lane that does not count adds exact
+// zeros (every intermediate is finite: r2 + eps > 0, rho > 0, the table index is clamped), so the sums are bitwise those
+// of force_visit; with no branch between them the compiler can overlap the dependent chains of consecutive visits
+template <class DwFn>
+__device__ __forceinline__ void force_visit_masked(const PairConst &pc, double inv_h, const double4 &A, const double4 &B, const double4 &C,
+                                                   const Nbr &j, bool act, DwFn dw_of, ForceSums &f) {
+#pragma clang fp contract(off)
+    const double n0 = A.x - j.x, n1 = A.y - j.y, n2 = A.z - j.z;
+    const double r2 = fma(n2, n2, fma(n1, n1, n0 * n0));
+    double dr, rs;
+    fast_sqrt_rsqrt(r2, dr, rs);
+    const double qi = dr * inv_h;
+    const bool on = act && qi <= 2.0 && r2 > 0.0;
+    const double v0 = B.x - j.vx, v1 = B.y - j.vy, v2 = B.z - j.vz;
+    const double vdotr = fmin(fma(v2, n2, fma(v1, n1, v0 * n0)), 0.0);
+    const double dWm = dw_of(fmin(qi, 2.0)) * rs;
+    const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;
+    const double vdotgradW = fma(g2, v2, fma(g1, v1, g0 * v0));
+    const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);
+    const double cbar = C.x + j.c_h;
+    const double abar = C.y + j.al_h;
+    const double visc = ((abar * vis_nu) * fma(2.0, vis_nu, -cbar)) * fast_rcp(B.w + j.rho_h);
+    const double Cf = (C.z + j.P_r2) + visc;
+    const double mj = on ? j.m : 0.0;
+    const double mC = mj * Cf;
+    f.s0 = fma(mC, g0, f.s0); f.s1 = fma(mC, g1, f.s1); f.s2 = fma(mC, g2, f.s2);
+    const double mv = mj * vdotgradW;
+    f.sdu = fma(mv, fma(0.5, visc, C.z), f.sdu);
+    f.sdal = f.sdal + mv;
+}
+
+template <class DwFn>
+__device__ __forceinline__ void force_visit(const PairConst &pc, double inv_h, const double4 &A, const double4 &B, const double4 &C,
+                                            const Nbr &j, bool act, DwFn dw_of, ForceSums &f) {
+#pragma clang fp contract(off)
+    const double n0 = A.x - j.x, n1 = A.y - j.y, n2 = A.z - j.z;                  // [F]:356
+    const double r2 = fma(n2, n2, fma(n1, n1, n0 * n0));
+    double dr, rs;
+    fast_sqrt_rsqrt(r2, dr, rs);                                                  // [F]:357
+    const double qi = dr * inv_h;
+    if (act && qi <= 2.0 && r2 > 0.0) {
+        const double v0 = B.x - j.vx, v1 = B.y - j.vy, v2 = B.z - j.vz;           // [F]:358
+        const double vdotr = fmin(fma(v2, n2, fma(v1, n1, v0 * n0)), 0.0);        // [F]:359-361
+        const double dWm = dw_of(qi) * rs;                                        // [F]:366; rs: the 1/dr of [F]:363
+        const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                 // [F]:363,368
+        const double vdotgradW = fma(g2, v2, fma(g1, v1, g0 * v0));               // [F]:370
+        const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);     // [F]:373
+        const double cbar = C.x + j.c_h;                                          // [F]:374 (halves stored)
+        const double abar = C.y + j.al_h;                                         // [F]:376
+        const double visc = ((abar * vis_nu) * fma(2.0, vis_nu, -cbar)) * fast_rcp(B.w + j.rho_h);   // [F]:378
+        const double Cf = (C.z + j.P_r2) + visc;                                  // [F]:381-382
+        const double mC = j.m * Cf;
+        f.s0 = fma(mC, g0, f.s0); f.s1 = fma(mC, g1, f.s1); f.s2 = fma(mC, g2, f.s2);   // [F]:383
+        const double mv = j.m * vdotgradW;
+        f.sdu = fma(mv, fma(0.5, visc, C.z), f.sdu);                              // [F]:387
+        f.sdal = f.sdal + mv;                                                     // [F]:390
+    }
+}
+
+// zero_rates [+ the self-gravity term already in ax..az, [F]:824-825], then the gas side of sink_gravforces, [F]:567-576
+__device__ __forceinline__ void sink_gas_accel(const PairConst &pc, const double *__restrict__ sink, const double4 &A, int64_t i,
+                                               const double *__restrict__ ax, const double *__restrict__ ay,
+                                               const double *__restrict__ az, double &a0, double &a1, double &a2) {
+    a0 = pc.grav ? ax[i] : 0.0; a1 = pc.grav ? ay[i] : 0.0; a2 = pc.grav ? az[i] : 0.0;
+    for (int s = 0; s < pc.ns; s++) {
+        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
+        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        const double d3 = dr * dr * dr;
+        const double ms = sink[6 * MAX_SINKS + s];
+        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
+    }
+}
+
+// rates of particle i from its sums (fixed h): sink gravity, normalisation, the alpha rate of [F]:316-318
+// (rho_i = 2 B.w, c_i = 2 C.x, alpha_i = 2 C.y: exact)
+__device__ __forceinline__ void force_epilogue(const PairConst &pc, const double *__restrict__ sink, int64_t i, const double4 &A,
+                                               const double4 &B, const double4 &C, const ForceSums &f, double *__restrict__ ax,
+                                               double *__restrict__ ay, double *__restrict__ az, double *__restrict__ du,
+                                               double *__restrict__ dalpha) {
+    double a0, a1, a2;
+    sink_gas_accel(pc, sink, A, i, ax, ay, az, a0, a1, a2);
+    const double inv_dwn = 1.0 / pc.dwnorm;                                       // [F]:126, applied once
+    ax[i] = a0 - f.s0 * inv_dwn; ay[i] = a1 - f.s1 * inv_dwn; az[i] = a2 - f.s2 * inv_dwn;
+    du[i] = f.sdu * inv_dwn;
+    dalpha[i] = fmax((f.sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * C.y) * (2.0 * C.x) / pc.h);
+}
+
+// The dw table entry of knot k, recomputed in registers exactly as the host fills the table (api.hip host_tables,
+// SUMMER_SPH.f90:55-79; same operations, no contraction): lets a kernel give the table's 40 KB of LDS to its tile
+__device__ __forceinline__ double dw_knot(int k, double dq) {
+#pragma clang fp contract(off)
+    // one instruction stream for both branches of the table: s = q, (-3) s + 2.25 (s s)  or  s = 2 - q, 0 s + (-0.75) (s s)
+    // (0 * s + x == x exactly), selected per lane without control flow
+    const double q = (double)k * dq;
+    const bool inner = q <= 1.0;
+    const double sq = inner ? q : 2.0 - q;
+    const double c2 = inner ? 2.25 : -0.75, c1 = inner ? -3.0 : 0.0;
+    const double r = c1 * sq + c2 * (sq * sq);
+    return q <= 2.0 ? r : 0.0;
+}
+__device__ __forceinline__ double dw_lerp_computed(double qi, double inv_dq, double dq, int nq) {
+#pragma clang fp contract(off)
+    const double t = qi * inv_dq;
+    const int k = min((int)t, nq - 1);
+    const double a = t - (double)k;
+    return fma(a, dw_knot(k + 1, dq), (1.0 - a) * dw_knot(k, dq));
 }
 
 }  // namespace sph

@@ -95,16 +95,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
 // ------------------------------------------------------------------------------------------
 // density + EOS
 // ------------------------------------------------------------------------------------------
-// force gather record (FREC doubles): x y z m | vx vy vz rho/2 | P/rho^2  c/2  alpha/2  0
-// (halved values: 0.5*(a_i + a_j) == a_i/2 + a_j/2 exactly, which saves three multiplies per pair)
-__device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i, const double4 &pi, double vx, double vy,
-                                           double vz, double rho, double P, double c, double alpha) {
-    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
-    fr[0] = pi;
-    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
-    fr[2] = make_double4(P / (rho * rho), 0.5 * c, 0.5 * alpha, 0.0);       // [F]:381: P/(rho*rho)
-}
-
 // entry k of a lane's list: wave-strided dwords (PACKED = false, nlist_kernel) or the 4-packed layout of
 // the tiled list build (PACKED = true: component k%4 of the int4 at row k/4), both read in lockstep
 template <bool PACKED>
@@ -157,23 +147,10 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
         j1 = j2;
         if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
         if (k + 1 < cnt) p1 = drec[j1];          // idle lanes issue no gather
-        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
-        double dr, rs;
-        fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                   // [F]:446
-        const double qi = dr * inv_h;                                          // [F]:111
-        if (act && qi <= 2.0)                                                  // [F]:113
-            acc = fma(pj.w, table_lerp(lds_w, qi, inv_dq, pc.nq), acc);        // [F]:114-118,454
+        density_visit(pi, pj, act, lds_w, inv_h, inv_dq, pc.nq, acc);
     }
     if (!live) return;
-    // self term (r = 0 -> w_table(0)): the tree walk visits the particle's own leaf too, [F]:443-455
-    acc = fma(pi.w, lds_w[0], acc);
-    const double rhoi = acc / pc.wnorm;                                        // [F]:125
-    // EOS, [F]:465-466
-    const double ui = u[i];
-    const double Pi = pc.gamma_m1 * ui * rhoi;
-    const double ci = sqrt(pc.gamma * Pi / rhoi);
-    rho[i] = rhoi; P[i] = Pi; cs[i] = ci;
-    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi, ci, alpha[i]);
+    density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
 }
 
 // P, c and the force records from an unchanged rho (SPH_FLAG_REUSE_DENSITY)
@@ -191,7 +168,7 @@ __global__ __launch_bounds__(256) void eos_only_kernel(PairConst pc, int64_t n, 
     const double Pi = pc.gamma_m1 * u[i] * r;
     const double ci = sqrt(pc.gamma * Pi / r);
     P[i] = Pi; cs[i] = ci;
-    write_frec(frec, i, drec[i], vx[i], vy[i], vz[i], r, Pi, ci, alpha[i]);
+    write_frec(frec, i, drec[i], vx[i], vy[i], vz[i], r, Pi / (r * r), ci, alpha[i], pc.h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -227,21 +204,20 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const bool live = i < n && orig[i] < n_owned;
     const int self = i < n ? (int)i : (int)(n - 1);
     const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
-    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/rho^2 c/2 alpha/2 -
+    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | c/2 alpha/2 P/rho^2 -
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const int32_t *mine = list_base<PACKED>(nlist, w, cap, lane);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
-    // SPH sums, un-normalised: every term is linear in dW, so 1/(pi h^4) ([F]:126) is applied once at the end
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-
+    ForceSums f;
+    auto dw_of = [&](double q) { return table_lerp(lds_dw, q, inv_dq, pc.nq); };
     int j1 = 0 < cnt ? load_entry(mine + list_off<PACKED>(0)) : self;
     int j2 = 1 < cnt ? load_entry(mine + list_off<PACKED>(1)) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
-        const double4 Aj = A1, Bj = B1, Cj = C1;
+        const Nbr nb = nbr_of(A1, B1, C1);
         const bool act = k < cnt;
         j1 = j2;
         if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
@@ -249,48 +225,10 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
             fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
         }
-
-        const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;               // [F]:356
-        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-        double dr, rs;
-        fast_sqrt_rsqrt(r2, dr, rs);                                                  // [F]:357
-        const double qi = dr * inv_h;
-        // beyond 2h every term is exactly 0; r == 0 (coincident points): see DESIGN.md
-        if (act && qi <= 2.0 && r2 > 0.0) {
-            const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;           // [F]:358
-            const double vdotr = fmin(v0 * n0 + v1 * n1 + v2 * n2, 0.0);              // [F]:359-361
-            const double dWm = table_lerp(lds_dw, qi, inv_dq, pc.nq) * rs;            // [F]:366; rs: the 1/dr of [F]:363
-            const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                 // [F]:363,368
-            const double vdotgradW = g0 * v0 + g1 * v1 + g2 * v2;                     // [F]:370
-            const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);     // [F]:373
-            const double cbar = Cc.y + Cj.y;                                          // [F]:374 (halves stored)
-            const double abar = Cc.z + Cj.z;                                          // [F]:376
-            const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);   // [F]:378
-            const double Cf = Cc.x + Cj.x + visc;                                     // [F]:381-382
-            const double mj = Aj.w;
-            const double mC = mj * Cf;
-            s0 = fma(mC, g0, s0); s1 = fma(mC, g1, s1); s2 = fma(mC, g2, s2);         // [F]:383
-            const double mv = mj * vdotgradW;
-            sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                    // [F]:387
-            sdal += mv;                                                               // [F]:390
-        }
+        force_visit(pc, inv_h, A, B, Cc, nb, act, dw_of, f);
     }
     if (!live) return;
-
-    // zero_rates, then the gas side of sink_gravforces, [F]:567-576
-    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;   // [F]:824-825
-    for (int s = 0; s < pc.ns; s++) {
-        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
-        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-        const double d3 = dr * dr * dr;
-        const double ms = sink[6 * MAX_SINKS + s];
-        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
-    }
-    const double inv_dwn = 1.0 / pc.dwnorm;
-    ax[i] = a0 - s0 * inv_dwn; ay[i] = a1 - s1 * inv_dwn; az[i] = a2 - s2 * inv_dwn;
-    du[i] = sdu * inv_dwn;
-    // [F]:317; rho_i = 2 B.w, c_i = 2 Cc.y, alpha_i = 2 Cc.z (exact)
-    dalpha[i] = fmax((sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / pc.h);
+    force_epilogue(pc, sink, i, A, B, Cc, f, ax, ay, az, du, dalpha);
 }
 
 // ------------------------------------------------------------------------------------------

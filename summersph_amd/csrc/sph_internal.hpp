@@ -57,6 +57,7 @@ struct TimingSlot {
 struct sph_ctx {
     sph_params p;
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -87,15 +88,14 @@ struct sph_ctx {
 
     // gather records (array-of-structs: one particle = one or few cache lines)
     double *drec = nullptr;          // 4 doubles: x y z m
-    double *frec = nullptr;          // FREC doubles: x y z m vx vy vz rho P/rho^2 c alpha 0
+    double *frec = nullptr;          // FREC doubles: x y z m | vx vy vz rho/2 | c/2 alpha/2 P/rho^2 h (pair_common.hpp)
 
     // variable-h path ("SUMMER_SPH - Variable.f90"): extra gather records and the octree leaf boxes
     bool variable = false;
     bool tiled = true;               // fixed-h: LDS-staged neighbour-list build (tiled.hip) unless SPH_FLAG_NO_LDS_TILES
-    bool tiled_eval = false;         // fixed-h: LDS-staged density/forces too (SPH_FLAG_LDS_TILE_EVAL; slower)
     bool whole_tile = false;         // fixed-h: density/forces read the neighbours' {x,y,z,m} from one LDS tile per workgroup (tiled.hip)
-    bool wt_ok = false;              // ... and the last list build found that the workgroups' intervals fit the tile
-    int32_t wt_fit_pct = -1;         // percentage of workgroups that fit (-1: kernels off)
+    bool wt_ok = false, wt_ok_f = false;   // ... and the last list build found that the workgroups' intervals fit the tile (density / forces geometry)
+    int32_t wt_fit_pct = -1, wt_fit_pct_f = -1;   // percentage of workgroups that fit (-1: kernels off)
     bool packed_list = true;         // list layout: 4-packed (tiled build) or wave-strided dwords (nlist_kernel)
     double *prec = nullptr;          // 4 doubles: x y z h        (neighbour-list build)
     double *lrec = nullptr;          // 4 doubles: leaf centre x y z, reach = 2h + leaf_edge/2 (<0: unresolved)
@@ -145,6 +145,8 @@ struct sph_ctx {
     // nlist[(w*nl_cap + k)*64 + lane]  -> a wave reads 64 consecutive ints per k
     int32_t *nlist = nullptr; int32_t nl_cap = 0; int64_t nl_waves_cap = 0;
     int32_t *ncount = nullptr; int32_t *wave_max = nullptr;
+    int32_t *plan_d = nullptr, *plan_f = nullptr;   // whole-tile kernels: the tile intervals of every workgroup (density / forces geometry), per list build
+    int32_t *deal = nullptr;                        // forces_q: order of the targets within their workgroup (by list length)
     int32_t *ntail = nullptr;        // variable h: entries of the margin shell, stored from the end of the lane's column
     int32_t nl_max = 0; double nl_mean = 0.0;
 
@@ -226,8 +228,6 @@ hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const in
 hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, int stride, bool apply_dt);
 // LDS-tiled fixed-h kernels (tiled.hip; default)
 int nlist_build_tiled(sph_ctx *c);
-hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc);
-hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc);
 constexpr int WT_TILE_RECORDS = 3712;     // whole-tile kernels: {x,y,z,m} records per LDS tile (116 KB; + the kernel table <= 160 KB)
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part);

@@ -1,22 +1,17 @@
-// tiled.hip -- LDS-staged pair kernels for the fixed-h path (default; pairs.hip keeps the direct-gather
-// versions for A/B runs, SPH_FLAG_NO_LDS_TILES).
+// tiled.hip -- LDS-staged kernels of the fixed-h path: the neighbour-list build and the "whole tile" density / forces
+// kernels (pairs.hip keeps the direct-gather versions: thick domains, SPH_FLAG_NO_WHOLE_TILE, A/B runs).
 //
-// Why.  With direct gathers every pair visit fetches its neighbour's record through the texture
-// addresser (TA): 2 (density) or 6 (forces) scattered 16-B loads per lane and visit.  rocprofv3 shows
-// the TA ~76 % busy and the VALU ~40 % (profiles/r01_v2_rocprof_summary.txt): the gather path, not
-// arithmetic, bounds the kernels.  But the neighbours of 256 consecutive cell-sorted particles are
-// not scattered: they lie in THREE contiguous intervals of the sorted order, one per offset along the
-// slowest grid axis (cells of neighbouring columns are adjacent in memory, the fastest axis is the
-// short one).  So a workgroup stages those intervals chunk by chunk into LDS with fully coalesced
-// loads -- each record is fetched once per workgroup instead of once per pair -- and the pair loop
-// reads LDS.
+// Why.  With direct gathers every pair visit fetches its neighbour's record through the texture addresser (TA): 2
+// (density) or 6 (forces) scattered 16-B loads per lane and visit, and a divergent 16-byte gather costs the
+// vector-memory path about one lane per clock and CU however many lanes share a line (tests/tools/micro/): the TA, not
+// arithmetic or cache misses, bounds density_kernel / forces_kernel.  But the neighbours of a run of consecutive
+// cell-sorted particles are not scattered: they lie in THREE contiguous intervals of the sorted order, one per offset
+// along the slowest grid axis (cells of neighbouring columns are adjacent in memory, the fastest axis is the short one).
+// So a workgroup stages those intervals once, side by side, in LDS with coalesced loads and the pair loop -- the same
+// lock-step list walk as pairs.hip -- reads its neighbours from the tile.
 //
-// Neighbour list ("ELL, wave-strided, 4-packed"): entry k of particle i = (wave w, lane l) is component
-// k%4 of the int4 at nlist4[(w*cap4 + k/4)*64 + l].  Entries are appended while the intervals are
-// scanned in order, so each lane's list is ascending within an interval; the evaluation kernels walk
-// the same intervals and consume, per staged chunk, the entries that fall into it.  (Any chunk size
-// works: entries of one interval pass are ascending, and a lane that runs ahead only consumes entries
-// whose records are in the staged chunk anyway.)
+// Neighbour list ("ELL, wave-strided, 4-packed"): entry k of particle i = (wave w, lane l) is component k%4 of the int4
+// at nlist4[(w*cap4 + k/4)*64 + l].
 //
 // Replaces (citations: /root/reference/SUMMER_SPH.f90, "[F]"): the same reference code as pairs.hip --
 // density_tree_search/get_density [F]:398-457, get_pressure_and_sound_speed [F]:459-468,
@@ -30,30 +25,14 @@ namespace sph {
 
 namespace {
 
-constexpr int TB = 256;              // threads per workgroup = targets per workgroup
-constexpr int WT_BS = 1024;         // whole-tile kernels: threads (= targets) per workgroup, one workgroup per CU
-constexpr int WT_CAP = WT_TILE_RECORDS;   // ... and records per tile (116 KB of {x,y,z,m}; + 40 KB kernel table)
-constexpr int T_NL = 512;            // staged records per chunk: neighbour-list build (32 B each)
-// density / forces: chunk size and where the kernel table lives are template parameters, chosen by
-// measurement (launch_*_tiled): TABLDS = table staged in LDS (40 KB, limits workgroups per CU),
-// else read through L1 from a pair-packed copy {t[k], t[k+1]} (one 16-B load per visit).
-
-// lerp from the pair-packed global table: tp[k] = {t[k], t[k+1]}
-__device__ __forceinline__ double pair_lerp(const double2 *__restrict__ tp, double qi, double inv_dq, int nq) {
-    const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k;
-    const double2 v = tp[k];
-    return (1.0 - a) * v.x + a * v.y;
-}
-
-__device__ __forceinline__ int sel4(const int4 &v, int k) {
-    const int a = (k & 1) ? v.y : v.x, b = (k & 1) ? v.w : v.z;
-    return (k & 2) ? b : a;
-}
+constexpr int TB = 256;              // neighbour-list build: threads (= targets) per workgroup
+constexpr int T_NL = 512;            // ... and staged records per chunk (32 B each)
+constexpr int WT_BS = 1024;          // density_wt: threads (= targets) per workgroup, one workgroup per CU
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int LDS_RESERVE = 1024;    // static LDS of the kernels (interval scratch) + slack
 
 // The three candidate intervals [lo, hi) of a workgroup (one per offset o2 = -1, 0, +1 along the slowest
-// axis), from the per-target row ranges.  s_lo/s_hi: LDS scratch of 3 ints each.
+// axis), from the per-target row ranges.
 struct Rows {
     int jb[3], je[3];     // this target's three cell rows (o1 = -1, 0, +1) of the current o2
 };
@@ -91,7 +70,8 @@ __device__ __forceinline__ void block_interval(const Rows &r, int *s_lo, int *s_
 }
 
 // ------------------------------------------------------------------------------------------
-// neighbour list build: every j != i with |x_i - x_j|^2 <= rcut2
+// neighbour list build: every j != i with |x_i - x_j|^2 <= rcut2.  The workgroup stages its candidate intervals
+// chunk-wise (coalesced), each lane scans its 9 cell rows out of LDS and appends 16-byte quads to its list column.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__restrict__ drec,
                                                   const int32_t *__restrict__ cell_start, int64_t n, double rcut2, int32_t cap,
@@ -149,207 +129,15 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     }
 }
 
-// ---- the walk over a lane's packed list -----------------------------------------------------------
-struct ListCursor {
-    const int4 *mine;
-    int4 buf;
-    int k, cnt;
-    __device__ __forceinline__ void init(const int4 *base, int count) {
-        mine = base; k = 0; cnt = count;
-        buf = count > 0 ? base[0] : make_int4(0, 0, 0, 0);
-    }
-    __device__ __forceinline__ int cur() const { return sel4(buf, k); }
-    __device__ __forceinline__ void advance() {
-        k++;
-        if ((k & 3) == 0 && k < cnt) buf = mine[(size_t)(k >> 2) * 64];
-    }
-};
-
-// force gather record (FREC doubles): x y z m | vx vy vz rho/2 | P/rho^2  c/2  alpha/2  0
-__device__ __forceinline__ void write_frec_t(double *__restrict__ frec, int64_t i, const double4 &pi, double vx, double vy,
-                                             double vz, double rho, double P, double c, double alpha) {
-    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
-    fr[0] = pi;
-    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
-    fr[2] = make_double4(P / (rho * rho), 0.5 * c, 0.5 * alpha, 0.0);       // [F]:381: P/(rho*rho)
-}
-
 // ------------------------------------------------------------------------------------------
-// density + EOS
-// ------------------------------------------------------------------------------------------
-template <int T_DE, bool TABLDS>
-__global__ __launch_bounds__(TB) void density_tiled(GridDesc g, PairConst pc, const double4 *__restrict__ drec,
-                                                    const int32_t *__restrict__ cell_start, const int4 *__restrict__ nlist4,
-                                                    int32_t cap, const int32_t *__restrict__ ncount,
-                                                    const double *__restrict__ w_tab, const double2 *__restrict__ w_pair,
-                                                    int64_t n, const double *__restrict__ u,
-                                                    const double *__restrict__ alpha, const double *__restrict__ vx,
-                                                    const double *__restrict__ vy, const double *__restrict__ vz,
-                                                    double *__restrict__ rho, double *__restrict__ P, double *__restrict__ cs,
-                                                    double *__restrict__ frec, const int32_t *__restrict__ orig, int32_t n_owned) {
-    extern __shared__ double lds_dyn[];
-    double *lds_w = lds_dyn;                                               // nq+1 doubles (padded to even) if TABLDS
-    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TABLDS ? ((pc.nq + 2) & ~1) : 0));
-    __shared__ int s_lo[4], s_hi[4];
-    if (TABLDS)
-        for (int k = threadIdx.x; k <= pc.nq; k += TB) lds_w[k] = w_tab[k];
-
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int64_t w = i >> 6;
-    const bool live = i < n && orig[i] < n_owned;
-    const double4 pi = drec[i < n ? i : n - 1];
-    int cc[3];
-    cell_coords(g, pi.x, pi.y, pi.z, cc);
-    ListCursor lc;
-    lc.init(nlist4 + ((size_t)w * (cap >> 2)) * 64 + lane, live ? min(ncount[i], cap) : 0);
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    double acc = 0.0;
-
-#pragma unroll
-    for (int o2 = -1; o2 <= 1; o2++) {
-        Rows r;
-        target_rows(g, cell_start, cc, live, o2, r);
-        int lo, hi;
-        block_interval(r, s_lo, s_hi, lo, hi);
-        for (int cb = lo; cb < hi; cb += T_DE) {
-            const int ce = min(cb + T_DE, hi);
-            __syncthreads();
-            for (int t = threadIdx.x; t < ce - cb; t += TB) tile[t] = drec[cb + t];
-            __syncthreads();
-            while (true) {
-                const int j = lc.cur();
-                const bool has = lc.k < lc.cnt && j >= cb && j < ce;
-                if (!__any(has)) break;
-                if (has) {
-                    const double4 pj = tile[j - cb];
-                    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
-                    double dr, rs;
-                    fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                   // [F]:446
-                    const double qi = dr * inv_h;                                          // [F]:111
-                    if (qi <= 2.0)                                                         // [F]:113-118,454
-                        acc = fma(pj.w, TABLDS ? table_lerp(lds_w, qi, inv_dq, pc.nq) : pair_lerp(w_pair, qi, inv_dq, pc.nq), acc);
-                    lc.advance();
-                }
-            }
-        }
-    }
-    if (!live) return;
-    acc = fma(pi.w, w_tab[0], acc);            // self term, r = 0 ([F]:443-455 visits the particle's own leaf)
-    const double rhoi = acc / pc.wnorm;                                                    // [F]:125
-    const double ui = u[i];
-    const double Pi = pc.gamma_m1 * ui * rhoi;                                             // [F]:465
-    const double ci = sqrt(pc.gamma * Pi / rhoi);                                          // [F]:466
-    rho[i] = rhoi; P[i] = Pi; cs[i] = ci;
-    write_frec_t(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi, ci, alpha[i]);
-}
-
-// ------------------------------------------------------------------------------------------
-// forces
-// ------------------------------------------------------------------------------------------
-template <int T_FO, bool TABLDS>
-__global__ __launch_bounds__(TB) void forces_tiled(GridDesc g, PairConst pc, const double *__restrict__ frec,
-                                                   const int32_t *__restrict__ cell_start, const int4 *__restrict__ nlist4,
-                                                   int32_t cap, const int32_t *__restrict__ ncount,
-                                                   const double *__restrict__ dw_tab, const double2 *__restrict__ dw_pair,
-                                                   const double *__restrict__ sink, int64_t n,
-                                                   double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
-                                                   double *__restrict__ du, double *__restrict__ dalpha,
-                                                   const int32_t *__restrict__ orig, int32_t n_owned) {
-    extern __shared__ double lds_dyn[];
-    double *lds_dw = lds_dyn;
-    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TABLDS ? ((pc.nq + 2) & ~1) : 0));   // T_FO * 3 double4
-    __shared__ int s_lo[4], s_hi[4];
-    if (TABLDS)
-        for (int k = threadIdx.x; k <= pc.nq; k += TB) lds_dw[k] = dw_tab[k];
-
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int64_t w = i >> 6;
-    const bool live = i < n && orig[i] < n_owned;
-    const int64_t self = i < n ? i : n - 1;
-    const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
-    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/rho^2 c/2 alpha/2 -
-    int cc[3];
-    cell_coords(g, A.x, A.y, A.z, cc);
-    ListCursor lc;
-    lc.init(nlist4 + ((size_t)w * (cap >> 2)) * 64 + lane, live ? min(ncount[i], cap) : 0);
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    const double4 *fg = reinterpret_cast<const double4 *>(frec);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-
-#pragma unroll
-    for (int o2 = -1; o2 <= 1; o2++) {
-        Rows r;
-        target_rows(g, cell_start, cc, live, o2, r);
-        int lo, hi;
-        block_interval(r, s_lo, s_hi, lo, hi);
-        for (int cb = lo; cb < hi; cb += T_FO) {
-            const int ce = min(cb + T_FO, hi);
-            __syncthreads();
-            for (int t = threadIdx.x; t < (ce - cb) * 3; t += TB) tile[t] = fg[(size_t)cb * 3 + t];
-            __syncthreads();
-            while (true) {
-                const int j = lc.cur();
-                const bool has = lc.k < lc.cnt && j >= cb && j < ce;
-                if (!__any(has)) break;
-                if (has) {
-                    const double4 *tj = tile + (j - cb) * 3;
-                    const double4 Aj = tj[0], Bj = tj[1], Cj = tj[2];
-                    const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;           // [F]:356
-                    const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-                    double dr, rs;
-                    fast_sqrt_rsqrt(r2, dr, rs);                                              // [F]:357
-                    const double qi = dr * inv_h;
-                    if (qi <= 2.0 && r2 > 0.0) {       // beyond 2h all terms are 0; r == 0: coincident points, DESIGN.md
-                        const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;       // [F]:358
-                        const double vdotr = fmin(v0 * n0 + v1 * n1 + v2 * n2, 0.0);          // [F]:359-361
-                        const double dWm = (TABLDS ? table_lerp(lds_dw, qi, inv_dq, pc.nq)
-                                                   : pair_lerp(dw_pair, qi, inv_dq, pc.nq)) * rs;  // [F]:366; rs = 1/dr of [F]:363
-                        const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;             // [F]:363,368
-                        const double vdotgradW = g0 * v0 + g1 * v1 + g2 * v2;                 // [F]:370
-                        const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2); // [F]:373
-                        const double cbar = Cc.y + Cj.y, abar = Cc.z + Cj.z;                  // [F]:374,376 (halves stored)
-                        const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);   // [F]:378
-                        const double Cf = Cc.x + Cj.x + visc;                                 // [F]:381-382
-                        const double mC = Aj.w * Cf;
-                        s0 = fma(mC, g0, s0); s1 = fma(mC, g1, s1); s2 = fma(mC, g2, s2);     // [F]:383
-                        const double mv = Aj.w * vdotgradW;
-                        sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                // [F]:387
-                        sdal += mv;                                                           // [F]:390
-                    }
-                    lc.advance();
-                }
-            }
-        }
-    }
-    if (!live) return;
-    // zero_rates, then the gas side of sink_gravforces, [F]:567-576
-    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;   // [F]:824-825
-    for (int s = 0; s < pc.ns; s++) {
-        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
-        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-        const double d3 = dr * dr * dr;
-        const double ms = sink[6 * MAX_SINKS + s];
-        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
-    }
-    const double inv_dwn = 1.0 / pc.dwnorm;                                                   // [F]:126, applied once
-    ax[i] = a0 - s0 * inv_dwn; ay[i] = a1 - s1 * inv_dwn; az[i] = a2 - s2 * inv_dwn;
-    du[i] = sdu * inv_dwn;
-    // [F]:317; rho_i = 2 B.w, c_i = 2 Cc.y, alpha_i = 2 Cc.z (exact)
-    dalpha[i] = fmax((sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / pc.h);
-}
-
-// ------------------------------------------------------------------------------------------
-// "Whole tile" evaluation: the three candidate intervals of the workgroup are staged ONCE, side by side, and the
-// pair loop is the lockstep list walk of pairs.hip with the record fetched from LDS instead of through the texture
-// addresser.  A divergent 16-byte gather costs the vector-memory path about one lane per clock and CU
-// (tests/tools/micro/gather_lds.hip: 2.8-3.5x slower than the same gather out of LDS, staging included), and that
-// rate, not cache misses, bounds density_kernel / forces_kernel.  A list entry j becomes a tile slot by comparing it
-// with the three interval starts.  A workgroup whose intervals do not fit the tile (dense regions, thick domains,
-// workgroups that straddle two slices) walks its lists with the memory gathers of pairs.hip instead -- decided per
-// workgroup, so the LDS loop contains no vector-memory gather at all: its only vector loads are the list rows, read
-// as int4 (four entries) two rows ahead.  Same operations in the same order as pairs.hip: bitwise the same results.
+// "Whole tile" evaluation: the three candidate intervals of the workgroup are staged ONCE, side by side.  A list entry j
+// becomes a tile slot by comparing it with the three interval starts.  A workgroup whose intervals do not fit the tile
+// (dense regions, thick domains, workgroups that straddle two slices) walks its lists with the memory gathers of
+// pairs.hip instead -- decided per workgroup, so the LDS loop contains no fall-back gather: its vector loads are the list
+// rows, read as int4 (four entries) two rows ahead, and (forces) the part of the neighbour's record the tile does not hold.
+// Three conditions each cost a factor when violated (measured): no rarely-taken vector-memory branch inside
+// the LDS loop (the compiler then waits for vmcnt(0) before every use); list rows fetched with wave-uniform,
+// unconditional loads and a scalar trip count; enough waves per SIMD.
 // ------------------------------------------------------------------------------------------
 struct TileMap {
     int lo[3], len[3], base[3];
@@ -364,7 +152,7 @@ struct TileMap {
     }
 };
 
-// s_lo / s_hi: LDS scratch of 3 * NW ints each (NW = waves per workgroup); one barrier pair for the three intervals
+// s_lo / s_hi: LDS scratch of 3 * NW ints each (NW = waves per workgroup); one barrier for the three intervals
 template <int NW>
 __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__restrict__ cell_start, const int cc[3], bool live,
                                          int *s_lo, int *s_hi, TileMap &m) {
@@ -398,11 +186,42 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
     m.need = total;
 }
 
+__device__ __forceinline__ void load_plan(const int32_t *__restrict__ plan, int64_t group, TileMap &tm) {
+    const int32_t *p = plan + 8 * (size_t)group;
+    const int4 a = *reinterpret_cast<const int4 *>(p), b = *reinterpret_cast<const int4 *>(p + 4);      // two 16-byte loads
+    tm.lo[0] = a.x; tm.lo[1] = a.y; tm.lo[2] = a.z; tm.len[0] = a.w; tm.len[1] = b.x; tm.len[2] = b.y;
+    tm.base[0] = 0; tm.base[1] = a.w; tm.base[2] = a.w + b.x;
+    tm.need = b.z;
+}
+
 __device__ __forceinline__ size_t poff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
 
-template <int TCAP, int BS>
-__global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const double4 *__restrict__ drec,
-                                                 const int32_t *__restrict__ cell_start, const int32_t *__restrict__ nlist,
+// Staging: the three intervals form one index space, tile slot s <- record lo[q] + (s - base[q]); a record is UPR units
+// of 16 bytes; unit t of the tile goes to dst[SWZ ? q_unit(s) + part : t].  U loads in flight per thread: staging is
+// latency-bound (one workgroup per CU, nothing else to run), so what counts is the number of round trips.
+__device__ __forceinline__ int q_unit(int s) { return 6 * s + (s >> 3); }
+template <int BS, int U, int UPR, bool SWZ>
+__device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+    const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
+    const int count = UPR * tm.need;
+    for (int t0 = threadIdx.x; t0 < count; t0 += U * BS) {
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                              // unconditional (clamped) loads: plain registers
+            const int t = min(t0 + u * BS, count - 1), sl = t / UPR;
+            v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * BS, sl = t / UPR;
+            if (t < count) dst[SWZ ? q_unit(sl) + (t - UPR * sl) : t] = v[u];
+        }
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, const int32_t *__restrict__ plan, const double4 *__restrict__ drec,
+                                                 const int32_t *__restrict__ nlist,
                                                  int32_t cap, const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
                                                  const double *__restrict__ w_tab,
                                                  int64_t n, const double *__restrict__ u,
@@ -413,25 +232,18 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
     extern __shared__ double lds_dyn[];
     double *lds_w = lds_dyn;                                               // nq+1 doubles (padded to even)
     double4 *tile = reinterpret_cast<double4 *>(lds_dyn + ((pc.nq + 2) & ~1));
-    __shared__ int s_lo[3 * (BS / 64)], s_hi[3 * (BS / 64)];
+    const int64_t group = xcd_chunk(blockIdx.x, gridDim.x);
+    const int64_t i = group * BS + threadIdx.x;
+    TileMap tm;
+    load_plan(plan, group, tm);
+    const bool fits = tm.need <= tcap;                 // workgroup-uniform
+    if (fits) stage_tile<BS, 4, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
     for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_w[k] = w_tab[k];
-
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n && orig[i] < n_owned;
     const int self = i < n ? (int)i : (int)(n - 1);
     const double4 pi = drec[self];
-    int cc[3];
-    cell_coords(g, pi.x, pi.y, pi.z, cc);
-    TileMap tm;
-    tile_map<BS / 64>(g, cell_start, cc, live, s_lo, s_hi, tm);
-    const bool fits = tm.need <= TCAP;                 // workgroup-uniform
-    if (fits) {
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            for (int t = threadIdx.x; t < tm.len[q]; t += BS) tile[tm.base[q] + t] = drec[tm.lo[q] + t];
-    }
     __syncthreads();
     if ((i & ~(int64_t)63) >= n) return;
 
@@ -439,14 +251,6 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
     const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
     double acc = 0.0;
-    auto visit = [&](const double4 &pj, bool act) {
-        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
-        double dr, rs;
-        fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                   // [F]:446
-        const double qi = dr * inv_h;                                          // [F]:111
-        if (act && qi <= 2.0)                                                  // [F]:113-118,454
-            acc = fma(pj.w, table_lerp(lds_w, qi, inv_dq, pc.nq), acc);
-    };
     if (fits && kmax > 0) {
         // list rows as int4 (four entries), fetched two rows ahead with wave-uniform, unconditional loads
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
@@ -457,13 +261,11 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
         for (int r = 0; r < nrow; r++) {
             const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int k = 4 * r + v;
-                if (k < kmax) {                                     // wave-uniform
-                    const double4 pj = p1;
-                    p1 = tile[k + 1 < cnt ? tm.slot(v < 3 ? comp4(qa, v + 1) : qb.x) : 0];
-                    visit(pj, k < cnt);
-                }
+            for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the up to three trips past the
+                const int k = 4 * r + v;                  // wave's longest list are masked like any idle lane, and without
+                const double4 pj = p1;                    // the branch the pipeline registers rotate by renaming, not by moves
+                p1 = tile[k + 1 < cnt ? tm.slot(v < 3 ? comp4(qa, v + 1) : qb.x) : 0];
+                density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
             }
             qa = qb; qb = qc;
         }
@@ -477,26 +279,26 @@ __global__ __launch_bounds__(BS) void density_wt(GridDesc g, PairConst pc, const
             j1 = j2;
             if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
             if (k + 1 < cnt) p1 = drec[j1];
-            visit(pj, k < cnt);
+            density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
         }
     }
     if (!live) return;
-    acc = fma(pi.w, lds_w[0], acc);            // self term, r = 0 ([F]:443-455 visits the particle's own leaf)
-    const double rhoi = acc / pc.wnorm;                                                    // [F]:125
-    const double ui = u[i];
-    const double Pi = pc.gamma_m1 * ui * rhoi;                                             // [F]:465
-    const double ci = sqrt(pc.gamma * Pi / rhoi);                                          // [F]:466
-    rho[i] = rhoi; P[i] = Pi; cs[i] = ci;
-    write_frec_t(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi, ci, alpha[i]);
+    density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
 }
 
-// forces: {x, y, z, m} of the neighbour from the LDS tile (the records density_wt stages), the other 64 bytes of its
-// record (v, rho/2 | P/rho^2, c/2, alpha/2) through the vector-memory path: 4 instead of 6 divergent 16-byte loads per
-// visit.  (The whole 96-byte record in LDS leaves room for one 256-thread workgroup per CU -- one wave per SIMD -- and
-// was measured slower than pairs.hip: 0.65-0.75 vs 0.54 ms.)
-template <int TCAP, int BS>
-__global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const double4 *__restrict__ drec, const double *__restrict__ frec,
-                                                const int32_t *__restrict__ cell_start, const int32_t *__restrict__ nlist,
+// forces.  The tile record holds the first REC of the neighbour's eleven values
+//     x y z m | vx vy vz rho/2 | P/rho^2 | c/2 alpha/2
+// and the rest still comes through the vector-memory path:
+//     REC = 4  {x,y,z,m}: four divergent 16-byte loads per visit remain (v, rho/2 | c/2, alpha/2, P/rho^2);
+//     REC = 9  all but {c/2, alpha/2}: ONE 16-byte load remains;
+//     REC = 11 everything: none.
+// Odd strides also spread a wave's scattered tile reads over all LDS banks.  What fits the 160 KB of a CU beside the
+// 40-KB dw table decides the workgroup size BS (candidates per target: 3.15 at 1024 targets, 3.3 at 512, 3.5 at 384);
+// TABLDS = false gives the table's 40 KB to the tile and recomputes the two table knots of a visit in registers
+// (bitwise the table's values, ~20 more fp64 instructions per visit).  Variants: launch_forces_wt.
+template <int BS, int REC, bool TABLDS>
+__global__ __launch_bounds__(BS) void forces_wt(PairConst pc, int32_t tcap, const int32_t *__restrict__ plan, const double *__restrict__ frec,
+                                                const int32_t *__restrict__ nlist,
                                                 int32_t cap, const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
                                                 const double *__restrict__ dw_tab,
                                                 const double *__restrict__ sink, int64_t n,
@@ -506,9 +308,9 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
                                                 const int32_t *__restrict__ wave_class, int32_t want) {
     extern __shared__ double lds_dyn[];
     double *lds_dw = lds_dyn;
-    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + ((pc.nq + 2) & ~1));
-    __shared__ int s_lo[3 * (BS / 64)], s_hi[3 * (BS / 64)];
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BS + threadIdx.x;
+    double *tile = lds_dyn + (TABLDS ? ((pc.nq + 2) & ~1) : 0);
+    const int64_t group = xcd_chunk(blockIdx.x, gridDim.x);
+    const int64_t i = group * BS + threadIdx.x;
     if (wave_class) {       // split evaluation (multi-GPU overlap): a block with no wave of class `want` leaves at once
         bool any = false;
         const int64_t w0 = (i - threadIdx.x) >> 6;
@@ -516,23 +318,32 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
             any |= ((w0 + k) << 6) < n && wave_class[w0 + k] == want;
         if (!any) return;
     }
-    for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_dw[k] = dw_tab[k];
+    const double4 *fg = reinterpret_cast<const double4 *>(frec);
+    TileMap tm;
+    load_plan(plan, group, tm);
+    const bool fits = tm.need <= tcap;
+    if (fits) {
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            for (int t = threadIdx.x; t < tm.len[q]; t += BS) {
+                const double4 *src = fg + (size_t)(tm.lo[q] + t) * 3;
+                double *dst = tile + (size_t)(tm.base[q] + t) * REC;
+                const double4 a = src[0];
+                dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+                if (REC > 4) {
+                    const double4 b = src[1], c = src[2];
+                    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w; dst[8] = c.z;
+                    if (REC > 9) { dst[9] = c.x; dst[10] = c.y; }
+                }
+            }
+    }
+    if (TABLDS)
+        for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_dw[k] = dw_tab[k];
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n && orig[i] < n_owned;
     const int self = i < n ? (int)i : (int)(n - 1);
-    const double4 *fg = reinterpret_cast<const double4 *>(frec);
     const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
-    int cc[3];
-    cell_coords(g, A.x, A.y, A.z, cc);
-    TileMap tm;
-    tile_map<BS / 64>(g, cell_start, cc, live, s_lo, s_hi, tm);
-    const bool fits = tm.need <= TCAP;
-    if (fits) {
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            for (int t = threadIdx.x; t < tm.len[q]; t += BS) tile[tm.base[q] + t] = drec[tm.lo[q] + t];
-    }
     __syncthreads();
     if ((i & ~(int64_t)63) >= n) return;
     if (wave_class && wave_class[w] != want) return;
@@ -540,49 +351,50 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
-    auto visit = [&](const double4 &Aj, const double4 &Bj, const double4 &Cj, bool act) {
-        const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;               // [F]:356
-        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-        double dr, rs;
-        fast_sqrt_rsqrt(r2, dr, rs);                                                  // [F]:357
-        const double qi = dr * inv_h;
-        if (act && qi <= 2.0 && r2 > 0.0) {
-            const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;           // [F]:358
-            const double vdotr = fmin(v0 * n0 + v1 * n1 + v2 * n2, 0.0);              // [F]:359-361
-            const double dWm = table_lerp(lds_dw, qi, inv_dq, pc.nq) * rs;            // [F]:366; rs = 1/dr of [F]:363
-            const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                 // [F]:363,368
-            const double vdotgradW = g0 * v0 + g1 * v1 + g2 * v2;                     // [F]:370
-            const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);     // [F]:373
-            const double cbar = Cc.y + Cj.y, abar = Cc.z + Cj.z;                      // [F]:374,376 (halves stored)
-            const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);   // [F]:378
-            const double Cf = Cc.x + Cj.x + visc;                                     // [F]:381-382
-            const double mC = Aj.w * Cf;
-            s0 = fma(mC, g0, s0); s1 = fma(mC, g1, s1); s2 = fma(mC, g2, s2);         // [F]:383
-            const double mv = Aj.w * vdotgradW;
-            sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                    // [F]:387
-            sdal += mv;                                                               // [F]:390
-        }
-    };
+    ForceSums f;
+    auto dw_of = [&](double q) { return TABLDS ? table_lerp(lds_dw, q, inv_dq, pc.nq) : dw_lerp_computed(q, inv_dq, pc.dq, pc.nq); };
     if (fits && kmax > 0) {
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
         const int nrow = (kmax + 3) >> 2;
         int4 qa = load_row(mine4);
         int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
         int jn = 0 < cnt ? qa.x : self;
-        double4 A1 = tile[0 < cnt ? tm.slot(jn) : 0];
-        double4 B1 = fg[(size_t)jn * 3 + 1], C1 = fg[(size_t)jn * 3 + 2];
+        // the pipeline registers: tile part (T1) and gathered part (G1 / H1) of the NEXT neighbour
+        double T1[REC];
+        double4 G1 = make_double4(0, 0, 0, 0), H1 = make_double4(0, 0, 0, 0);
+        double2 D1 = make_double2(0, 0);
+        {
+            const double *tp = tile + (size_t)(0 < cnt ? tm.slot(jn) : 0) * REC;
+#pragma unroll
+            for (int c = 0; c < REC; c++) T1[c] = tp[c];
+            if (REC == 4) { G1 = fg[(size_t)jn * 3 + 1]; H1 = fg[(size_t)jn * 3 + 2]; }
+            if (REC == 9) D1 = *reinterpret_cast<const double2 *>(frec + (size_t)jn * FREC + 8);
+        }
         for (int r = 0; r < nrow; r++) {
             const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 4 * r + v;
-                if (k < kmax) {                                     // wave-uniform
-                    const double4 Aj = A1, Bj = B1, Cj = C1;
+                {                                                   // whole rows, no trip-count test (see density_wt)
+                    Nbr nb;
+                    nb.x = T1[0]; nb.y = T1[1]; nb.z = T1[2]; nb.m = T1[3];
+                    if (REC == 4) {
+                        nb.vx = G1.x; nb.vy = G1.y; nb.vz = G1.z; nb.rho_h = G1.w; nb.c_h = H1.x; nb.al_h = H1.y; nb.P_r2 = H1.z;
+                    } else {
+                        nb.vx = T1[REC > 4 ? 4 : 0]; nb.vy = T1[REC > 4 ? 5 : 0]; nb.vz = T1[REC > 4 ? 6 : 0];
+                        nb.rho_h = T1[REC > 4 ? 7 : 0]; nb.P_r2 = T1[REC > 4 ? 8 : 0];
+                        if (REC == 9) { nb.c_h = D1.x; nb.al_h = D1.y; } else { nb.c_h = T1[REC > 9 ? 9 : 0]; nb.al_h = T1[REC > 9 ? 10 : 0]; }
+                    }
                     jn = v < 3 ? comp4(qa, v + 1) : qb.x;
-                    A1 = tile[k + 1 < cnt ? tm.slot(jn) : 0];
-                    if (k + 1 < cnt) { B1 = fg[(size_t)jn * 3 + 1]; C1 = fg[(size_t)jn * 3 + 2]; }     // idle lanes issue no gather
-                    visit(Aj, Bj, Cj, k < cnt);
+                    const bool more = k + 1 < cnt;
+                    const double *tp = tile + (size_t)(more ? tm.slot(jn) : 0) * REC;
+#pragma unroll
+                    for (int c = 0; c < REC; c++) T1[c] = tp[c];
+                    if (more) {                                     // idle lanes issue no gather
+                        if (REC == 4) { G1 = fg[(size_t)jn * 3 + 1]; H1 = fg[(size_t)jn * 3 + 2]; }
+                        if (REC == 9) D1 = *reinterpret_cast<const double2 *>(frec + (size_t)jn * FREC + 8);
+                    }
+                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
                 }
             }
             qa = qb; qb = qc;
@@ -594,45 +406,262 @@ __global__ __launch_bounds__(BS) void forces_wt(GridDesc g, PairConst pc, const 
         const double4 *fj = fg + (size_t)j1 * 3;
         double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
         for (int k = 0; k < kmax; k++) {
-            const double4 Aj = A1, Bj = B1, Cj = C1;
+            const Nbr nb = nbr_of(A1, B1, C1);
             j1 = j2;
             if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
             if (k + 1 < cnt) { fj = fg + (size_t)j1 * 3; A1 = fj[0]; B1 = fj[1]; C1 = fj[2]; }
-            visit(Aj, Bj, Cj, k < cnt);
+            force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
         }
     }
     if (!live) return;
-    // zero_rates, then the gas side of sink_gravforces, [F]:567-576
-    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;   // [F]:824-825
-    for (int s = 0; s < pc.ns; s++) {
-        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
-        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-        const double d3 = dr * dr * dr;
-        const double ms = sink[6 * MAX_SINKS + s];
-        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
-    }
-    const double inv_dwn = 1.0 / pc.dwnorm;                                                   // [F]:126, applied once
-    ax[i] = a0 - s0 * inv_dwn; ay[i] = a1 - s1 * inv_dwn; az[i] = a2 - s2 * inv_dwn;
-    du[i] = sdu * inv_dwn;
-    dalpha[i] = fmax((sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / pc.h);
+    force_epilogue(pc, sink, i, A, B, Cc, f, ax, ay, az, du, dalpha);
 }
 
-// workgroups (of the whole-tile kernels' size) whose three intervals do not fit the tile -> flags[4]
-template <int TCAP, int BS>
-__global__ __launch_bounds__(BS) void wt_fit_probe(GridDesc g, const double4 *__restrict__ drec, const int32_t *__restrict__ cell_start,
-                                                   int64_t n, const int32_t *__restrict__ orig, int32_t n_owned, int32_t *__restrict__ flags) {
+
+// forces, LPT lanes per target.  A workgroup of BS threads owns BS / LPT consecutive targets; the LPT lanes of a target take
+// the LPT entries of a list row between them (lane s: component s of every row), so a trip is a row.  Why: (1) the tile of
+// BS / LPT targets is small enough to hold the neighbours' WHOLE 96-byte records beside the dw table -- no vector-memory
+// gather is left in the loop, only the list rows (4 bytes per lane, coalesced); (2) a workgroup still fills the CU's 16 wave
+// slots (4 per SIMD), which the one-lane-per-target kernels with a full-record tile could not (their tile then leaves room
+// for 384-512 targets = 6-8 waves, and they stall on LDS latency: measured 0.45-0.53 ms per launch for every tile record
+// and workgroup size against 0.45 ms for the round-1 kernel); (3) a wave's trip count is the longest of 64 / LPT lists
+// divided by LPT, not the longest of 64: fewer idle lane-trips.  Records sit at 96-byte stride; one extra 16-byte unit per
+// eight records spreads a wave's scattered 16-byte reads over all banks (6 s mod 16 alone hits the even units only).  The LPT partial sums of a target are added in a fixed tree (lane order), so results are reproducible;
+// they differ from the one-lane kernels' by summation order (parity tolerance, not bitwise).
+
+template <int BS, int LPT, int MODE>
+__global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
+                                               const int2 *__restrict__ deal,
+                                               const double *__restrict__ frec, const int32_t *__restrict__ nlist,
+                                               int32_t cap, const int32_t *__restrict__ ncount,
+                                               const double *__restrict__ dw_tab, const double *__restrict__ sink, int64_t n,
+                                               double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
+                                               double *__restrict__ du, double *__restrict__ dalpha,
+                                               const int32_t *__restrict__ orig, int32_t n_owned,
+                                               const int32_t *__restrict__ wave_class, int32_t want) {
+    static_assert(LPT == 4, "a list row holds four entries");
+    constexpr int T = BS / LPT;
+    extern __shared__ double lds_dyn[];
+    double *lds_dw = lds_dyn;
+    double2 *tile = reinterpret_cast<double2 *>(lds_dyn + ((pc.nq + 2) & ~1));
+    __shared__ int s_tgt[T];
+    const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x >> 2;
+    const double4 *fg = reinterpret_cast<const double4 *>(frec);
+    // the dw table once per workgroup: the kernel is persistent, one workgroup per CU walks over many groups of T targets
+    for (int t = threadIdx.x; t < ((pc.nq + 1) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
+    if (threadIdx.x == 0 && ((pc.nq + 1) & 1)) lds_dw[pc.nq] = dw_tab[pc.nq];
+    // workgroups b, b + 8, .. share an XCD (round-robin dispatch, speed only): XCD x works on one contiguous eighth of the
+    // groups, so that the up to nine workgroups that stage a record find it in that XCD's L2; its workgroups take the
+    // groups of that eighth in turn
+    const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
+    const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
+    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    auto dw_of = [&](double q) { return table_lerp(lds_dw, q, inv_dq, pc.nq); };
+    // what does not need the tile is fetched one group ahead: the plan and the dealt target of this thread
+    int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
+    TileMap tm_next;
+    int2 deal_next = make_int2(0, -1);
+    if (group < g_hi) {
+        load_plan(plan, group, tm_next);
+        if (group * T + tl < n) deal_next = deal[group * T + tl];
+    }
+    for (; group < g_hi; group += per) {
+        const int64_t base = group * T;
+        const TileMap tm = tm_next;
+        const int2 dl = deal_next;
+        if (group + per < g_hi) {
+            load_plan(plan, group + per, tm_next);
+            deal_next = (group + per) * T + tl < n ? deal[(group + per) * T + tl] : make_int2(0, -1);
+        }
+        if (wave_class) {       // split evaluation (multi-GPU overlap): classes are per 64 targets
+            bool any = false;
+            for (int k = 0; k < T / 64; k++)
+                any |= base + 64 * k < n && wave_class[(base >> 6) + k] == want;
+            if (!any) continue;
+        }
+        const bool fits = tm.need <= tcap;
+        __syncthreads();                        // the previous group's tile and sums are no longer read
+        if (fits) stage_tile<BS, 6, 6, true>(reinterpret_cast<const double2 *>(frec), tile, tm);       // every load of the tile in flight at once
+        // Targets are dealt to the waves in order of list length (deal_kernel, longest first): a wave's trip count is that
+        // of its longest list, and 16 consecutive particles of a disc column span midplane and surface (mean 12 rows,
+        // longest of 16: 19).  With every neighbour record in the tile the order costs nothing but the coalescing of the list
+        // rows (4 bytes per lane).  Each target's sums are its own, so the order does not touch the results.
+        const int64_t i = base + dl.x;
+        const bool live = dl.y >= 0 && (!wave_class || wave_class[i >> 6] == want);
+        const int self = i < n ? (int)i : (int)(n - 1);
+        const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
+        const int cnt = live ? dl.y : 0;
+        __syncthreads();
+        const int nrow = MODE >= 4 ? 0 : __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));     // MODE 4: no pair loop (profiling)
+        ForceSums f;
+        // this lane's entries: component `sub` of the rows of target i's list column
+        const int32_t *lp = nlist + (((size_t)(self >> 6) * (cap >> 2)) * 64 + (self & 63)) * 4 + sub;
+        if (nrow > 0) {
+            int ea = lp[0];
+            int eb = lp[(size_t)min(1, nrow - 1) * 256];
+            int ec = lp[(size_t)min(2, nrow - 1) * 256];
+            if (fits) {
+                const double2 *rp = tile + q_unit(sub < cnt ? tm.slot(ea) : 0);
+                double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
+                for (int r = 0; r < nrow; r++) {
+                    const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
+                    const int k = 4 * r + sub;
+                    rp = tile + q_unit(k + 4 < cnt ? tm.slot(eb) : 0);
+                    if (MODE < 3) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5]; }
+                    else { r0.x += 1e-9 * (double)eb; }
+                    eb = ec;
+                    ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
+                    // MODE: ablations for profiling (tests/tools): 1 = masked body, 2 = + no dw table look-up, 3 = + no tile reads
+                    if (MODE == 0 || MODE == 4) force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    else if (MODE == 1) force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    else force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, [&](double q) { return q * 0.25 - 0.5; }, f);
+                }
+            } else {
+                int j = sub < cnt ? ea : self;
+                double4 A1 = fg[(size_t)j * 3], B1 = fg[(size_t)j * 3 + 1], C1 = fg[(size_t)j * 3 + 2];
+                for (int r = 0; r < nrow; r++) {
+                    const Nbr nb = nbr_of(A1, B1, C1);
+                    const int k = 4 * r + sub;
+                    if (k + 4 < cnt) { j = eb; A1 = fg[(size_t)j * 3]; B1 = fg[(size_t)j * 3 + 1]; C1 = fg[(size_t)j * 3 + 2]; }
+                    eb = ec;
+                    ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
+                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                }
+            }
+        }
+        // the target's sums: (lane 0 + lane 1) + (lane 2 + lane 3), the same value in all four lanes
+#pragma unroll
+        for (int o = 1; o < LPT; o <<= 1) {
+            f.s0 += __shfl_xor(f.s0, o, 64); f.s1 += __shfl_xor(f.s1, o, 64); f.s2 += __shfl_xor(f.s2, o, 64);
+            f.sdu += __shfl_xor(f.sdu, o, 64); f.sdal += __shfl_xor(f.sdal, o, 64);
+        }
+        // the epilogue (sink gravity with its IEEE divisions and square root, the stores) by one thread per target instead
+        // of one lane in four of every wave; the sums travel through the first bytes of the tile, which nobody reads any more
+        __syncthreads();
+        double *s_sum = reinterpret_cast<double *>(tile);           // [11][T]
+        if (sub == 0) {
+            s_sum[0 * T + tl] = f.s0; s_sum[1 * T + tl] = f.s1; s_sum[2 * T + tl] = f.s2; s_sum[3 * T + tl] = f.sdu; s_sum[4 * T + tl] = f.sdal;
+            s_sum[5 * T + tl] = A.x; s_sum[6 * T + tl] = A.y; s_sum[7 * T + tl] = A.z; s_sum[8 * T + tl] = B.w; s_sum[9 * T + tl] = Cc.x;
+            s_sum[10 * T + tl] = Cc.y;
+            s_tgt[tl] = live ? (int)i : -1;
+        }
+        __syncthreads();
+        if (threadIdx.x < T && s_tgt[threadIdx.x] >= 0) {
+            const int t = threadIdx.x;
+            const double4 At = make_double4(s_sum[5 * T + t], s_sum[6 * T + t], s_sum[7 * T + t], 0.0), Bt = make_double4(0.0, 0.0, 0.0, s_sum[8 * T + t]),
+                          Ct = make_double4(s_sum[9 * T + t], s_sum[10 * T + t], 0.0, 0.0);
+            ForceSums ft;
+            ft.s0 = s_sum[0 * T + t]; ft.s1 = s_sum[1 * T + t]; ft.s2 = s_sum[2 * T + t]; ft.sdu = s_sum[3 * T + t]; ft.sdal = s_sum[4 * T + t];
+            force_epilogue(pc, sink, s_tgt[t], At, Bt, Ct, ft, ax, ay, az, du, dalpha);
+        }
+    }
+}
+
+// The tile plan of every workgroup of BS consecutive targets, made once per list build and read by every evaluation kernel
+// of that geometry (two density and two force passes per position set): plan[8 g + ...] = {lo0, lo1, lo2, len0, len1, len2,
+// need, 0}.  Workgroups whose three intervals do not fit a tile of tcap records are counted in *misfit.  (Computing the
+// intervals inside the evaluation kernels cost them 18 dependent cell-table reads per thread, two wave reductions and a
+// barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
+template <int BS>
+__global__ __launch_bounds__(BS) void wt_plan_kernel(GridDesc g, int32_t tcap, const double4 *__restrict__ drec, const int32_t *__restrict__ cell_start,
+                                                     int64_t n, const int32_t *__restrict__ orig, int32_t n_owned, int32_t *__restrict__ plan,
+                                                     int32_t *__restrict__ misfit) {
     __shared__ int s_lo[3 * (BS / 64)], s_hi[3 * (BS / 64)];
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BS + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
     const bool live = i < n && orig[i] < n_owned;
     const double4 pi = drec[i < n ? i : n - 1];
     int cc[3];
     cell_coords(g, pi.x, pi.y, pi.z, cc);
     TileMap tm;
     tile_map<BS / 64>(g, cell_start, cc, live, s_lo, s_hi, tm);
-    if (threadIdx.x == 0 && tm.need > TCAP) atomicAdd(&flags[4], 1);
+    if (threadIdx.x == 0) {
+        int32_t *p = plan + 8 * (size_t)blockIdx.x;
+        p[0] = tm.lo[0]; p[1] = tm.lo[1]; p[2] = tm.lo[2]; p[3] = tm.len[0]; p[4] = tm.len[1]; p[5] = tm.len[2]; p[6] = tm.need; p[7] = 0;
+        if (tm.need > tcap) atomicAdd(misfit, 1);
+    }
+}
+
+// forces_q deals the T targets of a workgroup to its waves in order of list length (longest first): deal[base + rank] =
+// {the target's index within the group, its list length}.  rank = number of targets of the group with a longer list (ties: lower index
+// first).  Once per list build.
+template <int T>
+__global__ __launch_bounds__(T) void deal_kernel(int64_t n, const int32_t *__restrict__ ncount, const int32_t *__restrict__ orig, int32_t n_owned,
+                                                 int32_t cap, int2 *__restrict__ deal) {
+    __shared__ int s_cnt[T];
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const int tl = threadIdx.x;
+    const int mine = (base + tl < n && orig[base + tl] < n_owned) ? min(ncount[base + tl], cap) : -1;      // -1: not a target
+    s_cnt[tl] = mine;
+    __syncthreads();
+    int before = 0;
+    for (int u = 0; u < T; u++) {
+        const int cu = s_cnt[u];
+        before += (cu > mine || (cu == mine && u < tl)) ? 1 : 0;
+    }
+    deal[base + before] = make_int2(tl, mine);
 }
 
 inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
+
+// ---- the forces kernel in use ---------------------------------------------------------------------------------------
+struct FwtVariant { int bs, rec; bool tablds; };   // bs = targets per workgroup
+// default chosen by measurement on the bench disc; SPH_FWT_VARIANT=<n> selects another for A/B runs
+const FwtVariant FWT_VARIANTS[] = {
+    {1024, 4, true},     // 0: round-1 kernel: {x,y,z,m} tile, 4 gathers
+    {448, 9, true},      // 1: 1 gather, table in LDS
+    {512, 9, false},     // 2: 1 gather, table recomputed
+    {512, 11, false},    // 3: 0 gathers, table recomputed
+    {384, 11, true},     // 4: 0 gathers, table in LDS
+    {384, 9, true},      // 5: 1 gather, table in LDS
+    {256, 11, true},     // 6
+    {768, 9, false},     // 7
+    {256, 12, true},     // 8: forces_q: persistent, 1024 threads, 4 lanes per target, whole records in the tile, table in LDS
+    {256, 12, true}, {256, 12, true}, {256, 12, true}, {256, 12, true},   // 9-12: forces_q ablations (profiling only)
+};
+constexpr int FWT_DEFAULT = 8;
+
+int fwt_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SPH_FWT_VARIANT");
+        v = e ? atoi(e) : FWT_DEFAULT;
+        if (v < 0 || v >= (int)(sizeof(FWT_VARIANTS) / sizeof(FWT_VARIANTS[0]))) v = FWT_DEFAULT;
+    }
+    return v;
+}
+
+int32_t tile_cap(int nq, int rec, bool tablds) {
+    const size_t tab = tablds ? (size_t)((nq + 2) & ~1) * sizeof(double) : 0;
+    if (tab + LDS_RESERVE >= (size_t)LDS_BYTES) return 0;
+    return (int32_t)(((size_t)LDS_BYTES - LDS_RESERVE - tab) / ((size_t)rec * sizeof(double)));
+}
+
+// forces_q: 6 units of 16 bytes per record + 1 per eight records
+int32_t tile_cap_q(int nq) {
+    const size_t tab = (size_t)((nq + 2) & ~1) * sizeof(double);
+    constexpr size_t reserve = 4096;            // static LDS of forces_q
+    if (tab + reserve + 64 >= (size_t)LDS_BYTES) return 0;
+    const size_t units = ((size_t)LDS_BYTES - reserve - tab) / 16 - 2;
+    return (int32_t)((units * 8) / 49);
+}
+
+template <int BS>
+hipError_t plan_launch(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit) {
+    wt_plan_kernel<BS><<<dim3((unsigned)((c->n + BS - 1) / BS)), dim3(BS), 0, c->stream>>>(
+        c->grid, tcap, reinterpret_cast<const double4 *>(c->drec), c->cell_start, c->n, c->orig, (int32_t)c->n_owned, plan, misfit);
+    return hipGetLastError();
+}
+
+hipError_t plan_bs(sph_ctx *c, int bs, int32_t tcap, int32_t *plan, int32_t *misfit) {
+    switch (bs) {
+        case 1024: return plan_launch<1024>(c, tcap, plan, misfit);
+        case 768: return plan_launch<768>(c, tcap, plan, misfit);
+        case 512: return plan_launch<512>(c, tcap, plan, misfit);
+        case 448: return plan_launch<448>(c, tcap, plan, misfit);
+        case 384: return plan_launch<384>(c, tcap, plan, misfit);
+        default: return plan_launch<256>(c, tcap, plan, misfit);
+    }
+}
 
 }  // namespace
 
@@ -649,13 +678,14 @@ int nlist_build_tiled(sph_ctx *c) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
     const PairConst pc = make_pair_const(c);
-    const unsigned wt_blocks = (unsigned)((n + WT_BS - 1) / WT_BS);
+    const FwtVariant fv = FWT_VARIANTS[fwt_variant()];
+    const unsigned d_blocks = (unsigned)((n + WT_BS - 1) / WT_BS), f_blocks = (unsigned)((n + fv.bs - 1) / fv.bs);
     if (c->whole_tile) {
-        TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, sizeof(int32_t), c->stream));
-        wt_fit_probe<WT_CAP, WT_BS><<<dim3(wt_blocks), dim3(WT_BS), 0, c->stream>>>(
-            c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start, n, c->orig, (int32_t)c->n_owned, c->d_flags);
-        TL_CHECK(hipGetLastError());
-        TL_CHECK(hipMemcpyAsync(c->h_pinned + 10, c->d_flags + 4, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        // how many workgroups of the density / forces geometry fit their tile: flags[4], flags[5]
+        TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, 2 * sizeof(int32_t), c->stream));
+        TL_CHECK(plan_bs(c, WT_BS, tile_cap(pc.nq, 4, true), c->plan_d, c->d_flags + 4));
+        TL_CHECK(plan_bs(c, fv.bs, fv.rec == 12 ? tile_cap_q(pc.nq) : tile_cap(pc.nq, fv.rec, fv.tablds), c->plan_f, c->d_flags + 5));
+        TL_CHECK(hipMemcpyAsync(c->h_pinned + 10, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     }
     for (int attempt = 0; attempt < 8; attempt++) {
         TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
@@ -670,11 +700,21 @@ int nlist_build_tiled(sph_ctx *c) {
         if (c->whole_tile) {
             // the whole-tile kernels pay a prologue and run their fall-back loop at one workgroup per CU: use them when
             // (nearly) every workgroup's intervals fit the tile -- thin discs and sheets; thick domains keep pairs.hip
-            const int32_t misfit = *reinterpret_cast<int32_t *>(c->h_pinned + 10);
-            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)misfit) / std::max<int64_t>(wt_blocks, 1));
-            c->wt_ok = (int64_t)misfit * 10 <= (int64_t)wt_blocks;
+            const int32_t *mis = reinterpret_cast<int32_t *>(c->h_pinned + 10);
+            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)mis[0]) / std::max<int64_t>(d_blocks, 1));
+            c->wt_ok = (int64_t)mis[0] * 10 <= (int64_t)d_blocks;
+            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)mis[1]) / std::max<int64_t>(f_blocks, 1));
+            c->wt_ok_f = (int64_t)mis[1] * 10 <= (int64_t)f_blocks;
         }
-        if (mx <= c->nl_cap) { c->nlist_builds++; return SPH_OK; }
+        if (mx <= c->nl_cap) {
+            if (c->whole_tile && fv.rec == 12) {
+                deal_kernel<256><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
+                                                                                                  reinterpret_cast<int2 *>(c->deal));
+                TL_CHECK(hipGetLastError());
+            }
+            c->nlist_builds++;
+            return SPH_OK;
+        }
         ctx_free(c, c->nlist);
         c->nl_cap = ((mx + mx / 8 + 8) + 3) & ~3;
         if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
@@ -683,81 +723,69 @@ int nlist_build_tiled(sph_ctx *c) {
     return SPH_ERR_STATE;
 }
 
-static int tile_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SPH_TILE_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
-template <int T, bool TABLDS>
-static hipError_t density_tiled_launch(sph_ctx *c, const PairConst &pc) {
-    const size_t lds = (TABLDS ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)T * sizeof(double4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_tiled<T, TABLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    density_tiled<T, TABLDS><<<dim3(tb_blocks(c->n)), dim3(TB), lds, c->stream>>>(
-        c->grid, pc, reinterpret_cast<const double4 *>(c->drec), c->cell_start, reinterpret_cast<const int4 *>(c->nlist), c->nl_cap,
-        c->ncount, c->w_tab, reinterpret_cast<const double2 *>(c->w_pair), c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
-        c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
-    return hipGetLastError();
-}
-
-template <int T, bool TABLDS>
-static hipError_t forces_tiled_launch(sph_ctx *c, const PairConst &pc) {
-    const size_t lds = (TABLDS ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)T * 3 * sizeof(double4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_tiled<T, TABLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    forces_tiled<T, TABLDS><<<dim3(tb_blocks(c->n)), dim3(TB), lds, c->stream>>>(
-        c->grid, pc, c->frec, c->cell_start, reinterpret_cast<const int4 *>(c->nlist), c->nl_cap, c->ncount, c->dw_tab,
-        reinterpret_cast<const double2 *>(c->dw_pair), c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU],
-        c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
-    return hipGetLastError();
-}
-
-hipError_t launch_density_tiled(sph_ctx *c, const PairConst &pc) {
-    if (c->n == 0) return hipSuccess;
-    switch (tile_variant()) {
-        case 1: return density_tiled_launch<1216, true>(c, pc);
-        case 2: return density_tiled_launch<512, false>(c, pc);
-        case 3: return density_tiled_launch<512, true>(c, pc);
-        default: return density_tiled_launch<1216, false>(c, pc);
-    }
-}
-
-hipError_t launch_forces_tiled(sph_ctx *c, const PairConst &pc) {
-    if (c->n == 0) return hipSuccess;
-    switch (tile_variant()) {
-        case 1: return forces_tiled_launch<400, true>(c, pc);
-        case 2: return forces_tiled_launch<320, false>(c, pc);
-        case 3: return forces_tiled_launch<256, true>(c, pc);
-        default: return forces_tiled_launch<448, false>(c, pc);
-    }
-}
-
-
 // ---- whole-tile kernels -------------------------------------------------------------------------------------
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + (size_t)WT_CAP * sizeof(double4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_CAP, WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int32_t tcap = tile_cap(pc.nq, 4, true);
+    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + (size_t)tcap * sizeof(double4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    density_wt<WT_CAP, WT_BS><<<dim3((unsigned)((c->n + WT_BS - 1) / WT_BS)), dim3(WT_BS), lds, c->stream>>>(
-        c->grid, pc, reinterpret_cast<const double4 *>(c->drec), c->cell_start, c->nlist, c->nl_cap, c->ncount, c->wave_max,
+    density_wt<WT_BS><<<dim3((unsigned)((c->n + WT_BS - 1) / WT_BS)), dim3(WT_BS), lds, c->stream>>>(
+        pc, tcap, c->plan_d, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
         c->w_tab, c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
         c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
+    return hipGetLastError();
+}
+
+template <int BS, int REC, bool TABLDS>
+static hipError_t forces_wt_launch(sph_ctx *c, const PairConst &pc, int part) {
+    const int32_t tcap = tile_cap(pc.nq, REC, TABLDS);
+    const size_t lds = (TABLDS ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)tcap * REC * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_wt<BS, REC, TABLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    forces_wt<BS, REC, TABLDS><<<dim3((unsigned)((c->n + BS - 1) / BS)), dim3(BS), lds, c->stream>>>(
+        pc, tcap, c->plan_f, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max,
+        c->dw_tab, c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU],
+        c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned, part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
+    return hipGetLastError();
+}
+
+
+template <int MODE>
+static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
+    constexpr int BS = 1024, LPT = 4;
+    const int32_t tcap = tile_cap_q(pc.nq);
+    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    constexpr int T = BS / LPT;
+    const int64_t ngroups = (c->n + T - 1) / T;
+    const unsigned grid = (unsigned)std::min<int64_t>(ngroups, std::max(c->num_cus, 8));       // persistent: one workgroup per CU
+    forces_q<BS, LPT, MODE><<<dim3(grid), dim3(BS), lds, c->stream>>>(
+        pc, tcap, (int32_t)ngroups, c->plan_f, reinterpret_cast<const int2 *>(c->deal), c->frec, c->nlist, c->nl_cap, c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
+        c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
+        part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
     return hipGetLastError();
 }
 
 // part 0: every wave.  part 1 / 2: only the waves of class 0 (interior) / class 1, as launch_forces
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + (size_t)WT_CAP * sizeof(double4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_wt<WT_CAP, WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    forces_wt<WT_CAP, WT_BS><<<dim3((unsigned)((c->n + WT_BS - 1) / WT_BS)), dim3(WT_BS), lds, c->stream>>>(
-        c->grid, pc, reinterpret_cast<const double4 *>(c->drec), c->frec, c->cell_start, c->nlist, c->nl_cap, c->ncount, c->wave_max,
-        c->dw_tab, c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU],
-        c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned, part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
-    return hipGetLastError();
+    switch (fwt_variant()) {
+        case 0: return forces_wt_launch<1024, 4, true>(c, pc, part);
+        case 2: return forces_wt_launch<512, 9, false>(c, pc, part);
+        case 3: return forces_wt_launch<512, 11, false>(c, pc, part);
+        case 4: return forces_wt_launch<384, 11, true>(c, pc, part);
+        case 5: return forces_wt_launch<384, 9, true>(c, pc, part);
+        case 6: return forces_wt_launch<256, 11, true>(c, pc, part);
+        case 7: return forces_wt_launch<768, 9, false>(c, pc, part);
+        case 8: return forces_q_launch<0>(c, pc, part);
+        case 9: return forces_q_launch<1>(c, pc, part);
+        case 10: return forces_q_launch<2>(c, pc, part);
+        case 11: return forces_q_launch<3>(c, pc, part);
+        case 12: return forces_q_launch<4>(c, pc, part);
+        default: return forces_wt_launch<448, 9, true>(c, pc, part);
+    }
 }
 
 }  // namespace sph

@@ -328,15 +328,6 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     }
 }
 
-// force gather record (FREC doubles): x y z m | vx vy vz rho/2 | P/(Omega rho^2)  c/2  alpha/2  h
-__device__ __forceinline__ void write_frec_v(double *__restrict__ frec, int64_t i, const double4 &pm, double vx, double vy,
-                                             double vz, double rho, double om, double P, double c, double alpha, double h) {
-    double4 *fr = reinterpret_cast<double4 *>(frec + (size_t)i * FREC);
-    fr[0] = pm;
-    fr[1] = make_double4(vx, vy, vz, 0.5 * rho);
-    fr[2] = make_double4(P / (om * rho * rho), 0.5 * c, 0.5 * alpha, h);           // [V]:413
-}
-
 // ---- density + Omega + EOS ---------------------------------------------------------------------------
 __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const double4 *__restrict__ drec,
                                                            const int32_t *__restrict__ nlist, int32_t cap,
@@ -412,7 +403,7 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     const double Pi = pc.gamma_m1 * u[i] * rhoi;                                         // [V]:509
     const double ci = sqrt(pc.gamma * Pi / rhoi);                                        // [V]:510
     rho[i] = rhoi; omega[i] = omi; P[i] = Pi; cs[i] = ci;
-    write_frec_v(frec, i, pi, vx[i], vy[i], vz[i], rhoi, omi, Pi, ci, alpha[i], hi);
+    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi / (omi * rhoi * rhoi), ci, alpha[i], hi);           // [V]:413
 }
 
 __global__ __launch_bounds__(256) void eos_only_v_kernel(PairConst pc, int64_t n, const double4 *__restrict__ drec,
@@ -427,7 +418,7 @@ __global__ __launch_bounds__(256) void eos_only_v_kernel(PairConst pc, int64_t n
     const double Pi = pc.gamma_m1 * u[i] * r;
     const double ci = sqrt(pc.gamma * Pi / r);
     P[i] = Pi; cs[i] = ci;
-    write_frec_v(frec, i, drec[i], vx[i], vy[i], vz[i], r, omega[i], Pi, ci, alpha[i], hh[i]);
+    write_frec(frec, i, drec[i], vx[i], vy[i], vz[i], r, Pi / (omega[i] * r * r), ci, alpha[i], hh[i]);
 }
 
 // ---- forces, grad-h form ---------------------------------------------------------------------------------
@@ -449,7 +440,7 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const bool live = i < n && orig[i] < n_owned;
     const int self = i < n ? (int)i : (int)(n - 1);
     const double4 *fi = reinterpret_cast<const double4 *>(frec + (size_t)self * FREC);
-    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | P/(Om rho^2) c/2 alpha/2 h
+    const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | c/2 alpha/2 P/(Om rho^2) h
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
@@ -495,30 +486,24 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
             const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
             const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
             const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
-            const double cbar = Cc.y + Cj.y, abar = Cc.z + Cj.z;
+            const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
             const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
-            const double S = (Cc.x * dWo + Cj.x * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
+            const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
             const double mS = Aj.w * S;
             s0 = fma(mS, n0, s0); s1 = fma(mS, n1, s1); s2 = fma(mS, n2, s2);             // [V]:416
             const double mv = Aj.w * vdotgradW;
-            sdu = fma(mv, Cc.x + 0.5 * visc, sdu);                                        // [V]:419-421
+            sdu = fma(mv, Cc.z + 0.5 * visc, sdu);                                        // [V]:419-421
             sdal += mv;                                                                   // [V]:427
         }
     }
     if (!live) return;
     // zero_rates, [self-gravity], then the gas side of sink_gravforces ([V]:1028-1030, 691-)
-    double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;
-    for (int s = 0; s < pc.ns; s++) {
-        const double v0 = A.x - sink[0 * MAX_SINKS + s], v1 = A.y - sink[1 * MAX_SINKS + s], v2 = A.z - sink[2 * MAX_SINKS + s];
-        const double dr = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-        const double d3 = dr * dr * dr;
-        const double ms = sink[6 * MAX_SINKS + s];
-        a0 = a0 - (ms * (pc.G * v0 / d3)); a1 = a1 - (ms * (pc.G * v1 / d3)); a2 = a2 - (ms * (pc.G * v2 / d3));
-    }
+    double a0, a1, a2;
+    sink_gas_accel(pc, sink, A, i, ax, ay, az, a0, a1, a2);
     ax[i] = a0 - s0; ay[i] = a1 - s1; az[i] = a2 - s2;
     du[i] = sdu;
     // [V]:346
-    dalpha[i] = fmax(sdal / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.z) * (2.0 * Cc.y) / hi);
+    dalpha[i] = fmax(sdal / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.y) * (2.0 * Cc.x) / hi);
 }
 
 // ---- calc_smoothing -------------------------------------------------------------------------------------

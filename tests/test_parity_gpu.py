@@ -149,7 +149,7 @@ def test_direct_gather_kernels_vs_reference_fixture(capi, name):
     """the alternative kernel sets (per-lane-gather list build; chunk-staged density/forces; tiled list + direct gathers)
     stay correct"""
     g = load_golden(name)
-    for fl in (capi.FLAG_NO_LDS_TILES, capi.FLAG_LDS_TILE_EVAL, capi.FLAG_NO_WHOLE_TILE):
+    for fl in (capi.FLAG_NO_LDS_TILES, capi.FLAG_NO_WHOLE_TILE):
         ctx, gas, sinks = make_ctx(capi, g["ic"], flags=fl)
         ctx.density(); ctx.forces()
         for f in ("rho", "P", "c"):

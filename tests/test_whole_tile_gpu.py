@@ -1,7 +1,9 @@
-"""The whole-tile pair kernels (tiled.hip: neighbours' {x,y,z,m} from one LDS tile per workgroup, chosen per list build
-and per workgroup) against the direct-gather kernels of pairs.hip (SPH_FLAG_NO_WHOLE_TILE).  Both perform the same
-operations in the same order, so the comparison is bitwise; parity with the reference is what test_parity_gpu.py checks
-(it runs whichever kernels the context picks)."""
+"""The whole-tile pair kernels (tiled.hip: neighbours from one LDS tile per workgroup, chosen per list build and per
+workgroup) against the direct-gather kernels of pairs.hip (SPH_FLAG_NO_WHOLE_TILE).  density_wt performs the same
+operations in the same order: bitwise.  The forces kernel (forces_q) gives every target to four lanes, each with a
+quarter of the list, and adds the four partial sums in a fixed tree: every pair term is bitwise the same, the sums differ
+by summation order (<= 1e-14 of the field's scale, and reproducible).  Parity with the reference is what
+test_parity_gpu.py checks (it runs whichever kernels the context picks)."""
 import numpy as np
 import pytest
 
@@ -9,6 +11,13 @@ from summersph_amd import ic
 
 pytestmark = pytest.mark.gpu
 FIELDS = "rho P c ax ay az du dalpha".split()
+BITWISE = ("rho", "P", "c")
+
+
+def same(a, b, f, tol=1e-14):
+    if f in BITWISE:
+        return np.array_equal(a, b)
+    return float(np.max(np.abs(a - b))) <= tol * float(np.max(np.abs(b)))
 
 
 @pytest.fixture(scope="module")
@@ -62,9 +71,12 @@ def test_thin_disc_runs_from_the_tile_and_matches_bitwise(capi):
     gas, sinks = stirred_disc(200_000)
     a, sa = evaluate(capi, gas, sinks, 0)
     b, sb = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE)
-    assert sa.tile_fit_pct >= 90 and sb.tile_fit_pct == -1
+    assert sa.tile_fit_pct >= 90 and sa.tile_fit_pct_forces >= 90 and sb.tile_fit_pct == -1
     for f in FIELDS:
-        assert np.array_equal(a[f], b[f]), f
+        assert same(a[f], b[f], f), f
+    a2, _ = evaluate(capi, gas, sinks, 0)                      # reproducible: a second context gives the same bits
+    for f in FIELDS:
+        assert np.array_equal(a[f], a2[f]), f
 
 
 def test_ragged_size_and_trajectory(capi):
@@ -73,7 +85,7 @@ def test_ragged_size_and_trajectory(capi):
     b, _ = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE, steps=3)
     assert sa.tile_fit_pct >= 90
     for f in a:
-        assert np.array_equal(a[f], b[f]), f
+        assert float(np.max(np.abs(a[f] - b[f]))) <= 1e-12 * float(np.max(np.abs(b[f]))), f
 
 
 def test_thick_domain_keeps_the_gather_kernels(capi):
@@ -90,7 +102,7 @@ def test_thick_domain_keeps_the_gather_kernels(capi):
     b, _ = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE)
     assert 0 <= sa.tile_fit_pct < 90
     for f in FIELDS:
-        assert np.array_equal(a[f], b[f]), f
+        assert same(a[f], b[f], f), f
 
 
 def test_workgroups_that_do_not_fit_fall_back_inside_the_kernel(capi):
@@ -110,7 +122,7 @@ def test_workgroups_that_do_not_fit_fall_back_inside_the_kernel(capi):
     b, _ = evaluate(capi, both, sinks, capi.FLAG_NO_WHOLE_TILE)
     assert 90 <= sa.tile_fit_pct < 100
     for f in FIELDS:
-        assert np.array_equal(a[f], b[f]), f
+        assert same(a[f], b[f], f), f
 
 
 def test_counting_sort_gives_the_order_of_the_stable_radix_sort(tmp_path):
