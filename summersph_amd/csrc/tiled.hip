@@ -557,6 +557,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     }
 }
 
+
 // The tile plan of every workgroup of BS consecutive targets, made once per list build and read by every evaluation kernel
 // of that geometry (two density and two force passes per position set): plan[8 g + ...] = {lo0, lo1, lo2, len0, len1, len2,
 // need, 0}.  Workgroups whose three intervals do not fit a tile of tcap records are counted in *misfit.  (Computing the
@@ -722,6 +723,7 @@ int nlist_build_tiled(sph_ctx *c) {
     c->err = "neighbour list did not converge";
     return SPH_ERR_STATE;
 }
+
 
 // ---- whole-tile kernels -------------------------------------------------------------------------------------
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
