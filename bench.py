@@ -337,8 +337,18 @@ def main():
                 "workload": f"the headline disc with find_forces as the reference has it (Barnes-Hut gas self-gravity, "
                             f"theta 0.5) and the end-of-step sink accretion + boundary cull",
                 "value": args.n * fsteps / fel, "unit": "particle-steps/s", "ms_per_step": fel / fsteps * 1e3, "steps": fsteps,
-                "kernel_ms_per_step": {k: v[0] / fsteps for k, v in fkt.items()}, "particles_left": fctx.n}
+                "kernel_ms_per_step": {k: v[0] / fsteps for k, v in fkt.items()}, "particles_left": fctx.n, "final_dt": fdt}
             fctx.close()
+            # the same loop with SPH_FLAG_REUSE_GRAVITY: the start-of-step evaluation copies the Barnes-Hut term of the
+            # previous step's last walk (bitwise the same accelerations) -- reported beside the as-the-reference-runs number
+            gctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank,
+                                   capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL | capi.FLAG_REUSE_GRAVITY)
+            gel, gdt = timed_run(gctx, torch, fsteps, 1)
+            gkt = {k: gctx.timing_get(k) for k in capi.KERNELS}
+            out["full_simulate"]["reuse_gravity"] = {"value": args.n * fsteps / gel, "unit": "particle-steps/s", "ms_per_step": gel / fsteps * 1e3,
+                                                      "gravity_ms_per_step": gkt["gravity"][0] / fsteps, "final_dt": gdt,
+                                                      "note": "SPH_FLAG_REUSE_GRAVITY: one tree walk per step instead of two, same results bit for bit"}
+            gctx.close()
             if not args.reuse_density:
                 # the start-of-step density pass recomputes a bitwise identical rho (positions, masses, h unchanged
                 # since the end of the last step): SPH_FLAG_REUSE_DENSITY keeps it.  Reported beside the headline,

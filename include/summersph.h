@@ -89,6 +89,11 @@ typedef struct sph_params {
    configuration and is gone; the bit is ignored */
 #define SPH_FLAG_NO_WHOLE_TILE 128 /* fixed-h path: density/forces with the memory gathers of pairs.hip only, never the
                                    whole-tile kernels of tiled.hip (bitwise the same results); A/B measurements */
+#define SPH_FLAG_REUSE_GRAVITY 256 /* self-gravity: keep the Barnes-Hut term of the last walk and copy it instead of
+                                    walking again while positions, masses, h and the tree are unchanged -- the case of
+                                    the start-of-step evaluation, which sees the positions of the previous step's
+                                    last evaluation (bitwise the same accelerations); OFF by default: the reference
+                                    walks its tree in both evaluations ([F]:898,910) and the headline numbers do too */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
                                     change since the last one (bitwise the same rho); OFF by
                                     default: the reference recomputes it, [F]:896,908 */

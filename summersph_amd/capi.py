@@ -24,6 +24,7 @@ FLAG_SELF_GRAVITY = 16
 FLAG_ACCRETE_CULL = 32
 FLAG_SINK_CREATION = 64
 FLAG_NO_WHOLE_TILE = 128
+FLAG_REUSE_GRAVITY = 256
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [

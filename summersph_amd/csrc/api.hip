@@ -44,6 +44,8 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->sort_tmp);
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class); ctx_free(c, c->leaf_half);
     ctx_free(c, c->plan_d); ctx_free(c, c->plan_f); ctx_free(c, c->deal);
+    for (auto &g : c->g_cache) ctx_free(c, g);
+    c->grav_valid = false;
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
     ctx_free(c, c->prec); ctx_free(c, c->lrec); ctx_free(c, c->mkeys); ctx_free(c, c->mkeys_alt);
     ctx_free(c, c->mvals); ctx_free(c, c->mvals_alt); ctx_free(c, c->msort_tmp); ctx_free(c, c->h_new);
@@ -181,7 +183,7 @@ int do_density(sph_ctx *c) {
     if (!c->grid_valid) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
-        c->order_valid = true; c->derived_kept = false;
+        c->order_valid = true; c->derived_kept = false; c->grav_valid = false;
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         c->wave_class_valid = false; c->interior_done = false;
         if (c->variable) {
@@ -211,8 +213,25 @@ int do_forces(sph_ctx *c) {
     const PairConst pc = make_pair_const(c);
     if (c->gravity) {                                   // particle_gravforces, [F]:825 -- before the sink and SPH terms
         Timed t(c, SPH_K_GRAVITY);
-        if (!c->tree_valid) { API_TRY(gravity_tree_build(c)); c->tree_valid = true; }
-        API_HIP(launch_gravity(c));
+        const bool reuse = (c->p.flags & SPH_FLAG_REUSE_GRAVITY) != 0;
+        const size_t bytes = (size_t)c->n * sizeof(double);
+        if (reuse && c->grav_valid && c->tree_valid) {
+            // same positions, masses, h, tree and sorted order as at the last walk: the same accelerations, bit for bit
+            API_HIP(hipMemcpyAsync(c->f[SPH_F_AX], c->g_cache[0], bytes, hipMemcpyDeviceToDevice, c->stream));
+            API_HIP(hipMemcpyAsync(c->f[SPH_F_AY], c->g_cache[1], bytes, hipMemcpyDeviceToDevice, c->stream));
+            API_HIP(hipMemcpyAsync(c->f[SPH_F_AZ], c->g_cache[2], bytes, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            if (!c->tree_valid) { API_TRY(gravity_tree_build(c)); c->tree_valid = true; }
+            API_HIP(launch_gravity(c));
+            if (reuse) {
+                for (auto &g : c->g_cache)
+                    if (!g) API_TRY(ctx_alloc(c, &g, (size_t)c->cap, "gravity cache"));
+                API_HIP(hipMemcpyAsync(c->g_cache[0], c->f[SPH_F_AX], bytes, hipMemcpyDeviceToDevice, c->stream));
+                API_HIP(hipMemcpyAsync(c->g_cache[1], c->f[SPH_F_AY], bytes, hipMemcpyDeviceToDevice, c->stream));
+                API_HIP(hipMemcpyAsync(c->g_cache[2], c->f[SPH_F_AZ], bytes, hipMemcpyDeviceToDevice, c->stream));
+                c->grav_valid = true;
+            }
+        }
     }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
     { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : ((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc))); }
@@ -281,6 +300,7 @@ int do_update_h(sph_ctx *c) {
     // h changed: reaches, neighbour sets, rho all depend on it -- but nothing else does (do_density's short path)
     c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
     c->h_refresh_ok = true;
+    c->grav_valid = false;                              // the softening length of [V]:296 is the particle's own h
     return SPH_OK;
 }
 
@@ -330,6 +350,7 @@ void field_written(sph_ctx *c, int field) {
     if (field <= SPH_F_Z) c->order_valid = false;
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
     c->derived_kept = false;
+    c->grav_valid = false;
 }
 
 bool field_ready(const sph_ctx *c, int field) {
@@ -875,7 +896,7 @@ int sph_set_gravity_sources_dev(sph_ctx *c, int64_t n_src, const double *d_xyzm,
     c->gx_n = n_src;
     for (int a = 0; a < 6; a++) c->gx_box[a] = n_src > 0 ? lo_hi[a] : 0.0;
     c->gx_keys_valid = false;
-    c->tree_valid = false;
+    c->tree_valid = false; c->grav_valid = false;
     c->leaf_valid = false;
     c->rates_valid = false;
     if (c->variable) { c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; }      // the leaf boxes change

@@ -71,6 +71,17 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &s, double &rs)
     rs = h + h;
 }
 
+// rs = 1/sqrt(x) alone, x > 0 (two Newton steps on the hardware seed: ~1 ulp); the gravity walk needs the distance
+// itself only inside the softening support
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
 // lookup_kernel's interpolation (SUMMER_SPH.f90:114-118), table in LDS or global; returns the
 // un-normalised value.  k = min(int(q/dq), nq-1), a = (q - k dq)/dq are evaluated as q*(1/dq):
 // identical except within an ulp of a table knot, where the (continuous) interpolant changes by O(1e-16).

@@ -113,6 +113,8 @@ struct sph_ctx {
     // Barnes-Hut gas self-gravity (gravity.hip): binary radix tree over the octree path keys
     bool gravity = false;
     bool tree_valid = false;
+    double *g_cache[3] = {nullptr, nullptr, nullptr};   // SPH_FLAG_REUSE_GRAVITY: the self-gravity term of the last walk (sorted order)
+    bool grav_valid = false;                            // ... still that of the current positions, masses, h, tree and sorted order
     int32_t *g_left = nullptr, *g_right = nullptr, *g_parent = nullptr, *g_leaf_parent = nullptr, *g_prefix = nullptr;
     int32_t *g_flag = nullptr, *g_slot = nullptr, *g_lvl = nullptr, *g_rope = nullptr, *g_leaf_rope = nullptr;
     double *g_sum = nullptr, *g_leafA = nullptr;     // 4 doubles per node / leaf

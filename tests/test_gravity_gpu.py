@@ -141,3 +141,24 @@ def test_binary_two_sinks_full_loop(capi):
     s = ctx.get_sinks()
     assert np.max(np.abs(s["x"] - g["sph_s3_sx"])) <= 1e-12 and np.max(np.abs(s["vy"] - g["sph_s3_svy"])) <= 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("name,steps,extra", [("disc3000_traj", 5, 0), ("acc2000_traj", 3, "acc")])
+def test_reuse_gravity_is_bitwise_neutral(capi, name, steps, extra):
+    """SPH_FLAG_REUSE_GRAVITY: the start-of-step evaluation copies the Barnes-Hut term of the previous step's last walk
+    (same positions, masses, h, tree) instead of walking again -- same bits, also across steps that remove particles
+    (the cache is dropped with the tree)"""
+    g = load_golden(name)
+    flags = capi.FLAG_SELF_GRAVITY | (capi.FLAG_ACCRETE_CULL if extra == "acc" else 0)
+    out = []
+    for fl in (flags, flags | capi.FLAG_REUSE_GRAVITY):
+        ctx, gas, sinks = make_ctx(capi, g["ic"], flags=fl)
+        dts, t = [1e-2], 0.0
+        for _ in range(steps):
+            dt, t = ctx.step(dts[-1], t)
+            dts.append(dt)
+        out.append((dts, {f: ctx.field(f) for f in "x y z vx vy vz u alpha ax ay az".split()}, ctx.n))
+        ctx.close()
+    assert out[0][0] == out[1][0] == list(g["full_dt_seq"])[:steps + 1] and out[0][2] == out[1][2]
+    for f in out[0][1]:
+        assert np.array_equal(out[0][1][f], out[1][1][f]), f
