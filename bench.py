@@ -19,10 +19,14 @@ Workloads
                              headline (the >= 1e7 target of BASELINE.md is quoted on this config).
 
 Extra objects in the JSON line
-  roofline     dominant kernel (forces): ALGORITHMIC HBM bytes per launch (80 B read
-               + 40 B written per particle) / its mean launch duration, measured with HIP events on
-               the library's own stream during the timed steps; peak 8 TB/s; traffic = PMC bytes of
-               the committed rocprofv3 passes (profiles/) when they were taken on this workload size.
+  roofline     dominant kernel of the headline workload (the forces kernel): ALGORITHMIC HBM bytes per launch (SURVEY.md
+               8(d): 80 B read + 40 B written per particle) / its mean launch duration, measured with HIP events on the
+               library's own stream during the timed steps; peak 8 TB/s.  `traffic` (PMC bytes per launch) and `limiter`
+               (TA / vector-issue / LDS occupancy of that kernel) are quoted from profiles/r02_limiters.json -- the
+               rocprofv3 passes of profiles/r02_profile.sh on this code -- when they were taken on this workload size;
+               `limiter.lane_efficiency` is computed live.  `bound` names the resource that is busiest: the path's
+               compulsory HBM traffic is tiny, so it is never "hbm".  The `variable_h` and `full_simulate` records carry
+               their own roofline object (dominant kernels: the variable-h list build, the gravity tree walk).
   cpu_baseline the CPU oracle (oracle/sph_oracle.c, OpenMP over the host cores) timed on a bounded
                sample of the same workload on this box (rank 0, N = 1 only).
 """
@@ -46,6 +50,39 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64
 # fp64 operations per pair visit as written in the kernels (div/sqrt counted as 1 each)
 FLOPS_DENSITY_PAIR, FLOPS_FORCE_PAIR = 22, 75
+
+
+def load_limiters():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_limiters.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def roofline_record(limiters, workload, prefixes, alg_bytes, avg_launch_s, launches, lane_eff, n, default_n=1_000_000):
+    """roofline object of one kernel: algorithmic bytes / measured duration against the HBM peak, plus what the committed
+    counter passes say limits it (only when they were taken on this workload size)"""
+    achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    rec, name = None, None
+    if n == default_n:
+        for k, v in limiters.get(workload, {}).get("kernels", {}).items():
+            if any(k.startswith(p) for p in prefixes) and (rec is None or v.get("total_ms", 0) > rec.get("total_ms", 0)):
+                rec, name = v, k
+    limiter = {"lane_efficiency": lane_eff}
+    bound = "unmeasured (no counter pass for this workload size)"
+    if rec:
+        for key in ("ta_busy", "valu_issue", "valu_active", "lds_busy", "clock_GHz_est"):
+            if key in rec:
+                limiter[key] = rec[key]
+        limiter["hbm_frac_algorithmic"] = achieved / HBM_PEAK_GBS
+        cand = {"texture addresser (divergent gathers)": rec.get("ta_busy", 0.0), "fp64 vector issue": rec.get("valu_issue", 0.0),
+                "LDS": rec.get("lds_busy", 0.0), "hbm": (rec.get("traffic_bytes_per_launch", 0.0) / avg_launch_s / 1e9 / HBM_PEAK_GBS) if avg_launch_s > 0 else 0.0}
+        bound = max(cand, key=cand.get)
+        limiter["source"] = f"profiles/r02_limiters.json [{workload}][{name}] (profiles/r02_profile.sh, rocprofv3 counter passes)"
+        limiter["avg_launch_us_rocprof"] = rec.get("avg_us")
+    return {"bound": bound, "kernel": name or prefixes[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": rec.get("traffic_bytes_per_launch") if rec else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "limiter": limiter}
 
 
 def usable_cores():
@@ -269,14 +306,12 @@ def main():
         bps = BYTES_PER_STEP_VAR if variable else BYTES_PER_STEP
         pair_visits = 2 * 2 * st.nlist_mean * args.n * args.steps / elapsed
         flops = (FLOPS_DENSITY_PAIR + FLOPS_FORCE_PAIR) * 2 * st.nlist_mean * args.n * args.steps / elapsed / 1e12
-        # HBM traffic of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 on
-        # itself); only quoted when it was measured on this very workload
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_forces_traffic.json")
-        if os.path.exists(tf) and world == 1 and not variable and args.ic == "disc":
-            rec = json.load(open(tf))
-            if rec.get("workload_particles") == args.n and rec.get("kernel", "").startswith("forces_wt" if st.tile_fit_pct >= 90 else "forces_kernel"):
-                traffic, traffic_src = rec["traffic_bytes_per_launch"], rec.get("source")
+        limiters = load_limiters()
+        fk = ["forces_v_kernel"] if variable else (["forces_q", "forces_wt"] if st.tile_fit_pct_forces >= 90 else ["forces_kernel"])
+        wkey = "variable" if variable else ("full" if args.full_simulate else "fixed")
+        comparable = world == 1 and args.ic == "disc" and (args.full_simulate or not args.self_gravity)
+        roof = roofline_record(limiters if comparable else {}, wkey, fk, alg_bytes, f_avg_s, f_cnt,
+                               st.lane_efficiency_forces if not variable else (st.nlist_mean / st.nlist_wave_mean if st.nlist_wave_mean else None), args.n)
         wl = ((f"thin Keplerian ring (r ~ N(r0, 0.05 r0)), " if args.ic == "ring" and not variable else "uniform Keplerian disc, ")
               + f"{args.n} gas particles + 1 sink per GPU, "
               + ("variable h (BASELINE configs[2]: grad-h, leaf-box neighbour rule, h update every step), "
@@ -290,16 +325,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "mode": args.mode, "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean, "mean_wave_trips": st.nlist_wave_mean,
+                       "tile_fit_pct": st.tile_fit_pct, "tile_fit_pct_forces": st.tile_fit_pct_forces,
                        "max_neighbours": st.nlist_max, "grid": list(st.grid_dim), "reuse_density": bool(args.reuse_density),
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} x-slabs, ghost exchange + migration over "
                                       + ("RCCL (torch.distributed nccl)" if data_backend == "nccl" else "host-staged gloo messages"),
                        "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
-            "roofline": {"bound": "hbm", "kernel": "forces_v_kernel" if variable else ("forces_wt" if st.tile_fit_pct >= 90 else "forces_kernel"), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": f_avg_s * 1e3, "launches": f_cnt,
-                         "note": "compulsory HBM traffic is tiny for this path; the pair loop is bound by the L1/TA gather "
-                                 "path and fp64 VALU (profiles/), see valu_fp64"},
+            "roofline": roof,
             "valu_fp64": {"achieved_tflops_est": flops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": flops / FP64_PEAK_TFLOPS,
                           "pair_visits_per_s": pair_visits},
             "hbm_step": {"algorithmic_bytes_per_particle_step": bps, "achieved_GBs": bps * value / world / 1e9},
@@ -309,6 +341,8 @@ def main():
         copy_gbs = stream_copy_gbs(torch, local_rank)
         out["roofline"]["stream_copy_GBs"] = copy_gbs
         out["roofline"]["frac_of_stream_copy"] = achieved / copy_gbs
+        out["roofline"]["note"] = ("compulsory HBM traffic is tiny for this path (hbm_step); what the pair kernels wait for is "
+                                   "in `limiter`: fp64 vector issue, the LDS tile reads and idle lanes (lane_efficiency)")
         if sim is not None and sim.profile:
             out["dist_phase_ms_per_step_rank0"] = {k: 1e3 * v / args.steps for k, v in sim.phase_s.items()}
             out["dist_stats_rank0"] = dict(sim.stats)
@@ -325,7 +359,14 @@ def main():
                 "value": args.n * args.steps / vel, "unit": "particle-steps/s", "ms_per_step": vel / args.steps * 1e3,
                 "mean_list_entries": vst.nlist_mean, "mean_wave_trips": vst.nlist_wave_mean, "max_list_entries": vst.nlist_max, "grid": list(vst.grid_dim),
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in vkt.items()}, "final_dt": vdt,
-                "target_BASELINE_md": 1.0e7}
+                "target_BASELINE_md": 1.0e7,
+                # dominant kernel: the list build (nlist_v_tiled): reads {x,y,z,h} + leaf box + id (68 B), writes the entries
+                # (4 B each) and two counts (8 B) per particle
+                "roofline": roofline_record(limiters, "variable", ["nlist_v_tiled"], (68 + 8 + 4 * vst.nlist_mean) * args.n,
+                                            vkt["nlist"][0] / max(vkt["nlist"][1], 1) * 1e-3, vkt["nlist"][1],
+                                            vst.nlist_mean / vst.nlist_wave_mean if vst.nlist_wave_mean else None, args.n),
+                "hbm_step": {"algorithmic_bytes_per_particle_step": BYTES_PER_STEP_VAR,
+                             "achieved_GBs": BYTES_PER_STEP_VAR * args.n * args.steps / vel / 1e9}}
             vctx.close()
             # simulate() as the reference runs it: + Barnes-Hut gas self-gravity, accretion, boundary cull
             fctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank,
@@ -337,7 +378,10 @@ def main():
                 "workload": f"the headline disc with find_forces as the reference has it (Barnes-Hut gas self-gravity, "
                             f"theta 0.5) and the end-of-step sink accretion + boundary cull",
                 "value": args.n * fsteps / fel, "unit": "particle-steps/s", "ms_per_step": fel / fsteps * 1e3, "steps": fsteps,
-                "kernel_ms_per_step": {k: v[0] / fsteps for k, v in fkt.items()}, "particles_left": fctx.n, "final_dt": fdt}
+                "kernel_ms_per_step": {k: v[0] / fsteps for k, v in fkt.items()}, "particles_left": fctx.n, "final_dt": fdt,
+                # dominant kernel: the tree walk (grav_walk_wave): reads {x,y,z,m}, leaf and id (40 B), writes a (24 B) per particle
+                "roofline": roofline_record(limiters, "full", ["grav_walk_wave"], 64 * args.n,
+                                            fkt["grav_walk"][0] / max(fkt["grav_walk"][1], 1) * 1e-3, fkt["grav_walk"][1], None, args.n)}
             fctx.close()
             # the same loop with SPH_FLAG_REUSE_GRAVITY: the start-of-step evaluation copies the Barnes-Hut term of the
             # previous step's last walk (bitwise the same accelerations) -- reported beside the as-the-reference-runs number

@@ -118,6 +118,7 @@ enum sph_kernel_id {
     SPH_K_LEAF,        /* variable-h: octree leaf boxes (Morton keys, sort, depth)             */
     SPH_K_UPDATE_H,    /* variable-h: calc_smoothing                                          */
     SPH_K_GRAVITY,     /* self-gravity: octree keys, radix tree, node sums, tree walk          */
+    SPH_K_GRAV_WALK,   /* self-gravity: the tree walk alone (inside SPH_K_GRAVITY)             */
     SPH_K_COUNT
 };
 
@@ -136,6 +137,8 @@ typedef struct sph_stats {
     double  nlist_wave_mean;/* mean over wavefronts of the longest list in the wave = trips the pair kernels run */
     int32_t tile_fit_pct_forces; /* as tile_fit_pct, for the forces kernel's workgroup size and tile record            */
     int32_t reserved0;
+    double  lane_efficiency_forces; /* fixed h: list entries / lane-trips of the forces kernel in use (1 = no idle lanes):
+                                       forces_q deals targets by list length, so this is not nlist_mean / nlist_wave_mean */
 } sph_stats;
 
 /* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation

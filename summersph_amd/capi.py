@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SUMMERSPH_LIB", LIB_PATH)      # A/B builds of the sa
 _D = C.POINTER(C.c_double)
 
 FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha", "h", "omega"]
-KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h", "gravity"]
+KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h", "gravity", "grav_walk"]
 FLAG_REUSE_DENSITY = 1
 FLAG_VARIABLE_H = 2
 FLAG_NO_LDS_TILES = 4
@@ -58,7 +58,7 @@ class Stats(C.Structure):
                 ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("tile_fit_pct", C.c_int32), ("nlist_mean", C.c_double),
                 ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
                 ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double),
-                ("tile_fit_pct_forces", C.c_int32), ("reserved0", C.c_int32)]
+                ("tile_fit_pct_forces", C.c_int32), ("reserved0", C.c_int32), ("lane_efficiency_forces", C.c_double)]
 
 
 class SphError(RuntimeError):

@@ -222,7 +222,7 @@ int do_forces(sph_ctx *c) {
             API_HIP(hipMemcpyAsync(c->f[SPH_F_AZ], c->g_cache[2], bytes, hipMemcpyDeviceToDevice, c->stream));
         } else {
             if (!c->tree_valid) { API_TRY(gravity_tree_build(c)); c->tree_valid = true; }
-            API_HIP(launch_gravity(c));
+            { Timed tw(c, SPH_K_GRAV_WALK); API_HIP(launch_gravity(c)); }
             if (reuse) {
                 for (auto &g : c->g_cache)
                     if (!g) API_TRY(ctx_alloc(c, &g, (size_t)c->cap, "gravity cache"));
@@ -680,6 +680,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
             sw += m;
         }
         o->nlist_wave_mean = sw / (double)((cnt.size() + 63) / 64);
+        o->lane_efficiency_forces = (c->whole_tile && c->wt_ok_f) ? forces_lane_efficiency(cnt) : (sw > 0.0 ? s / (64.0 * sw) : 0.0);
     }
     return SPH_OK;
 }

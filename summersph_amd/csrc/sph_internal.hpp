@@ -233,6 +233,7 @@ int nlist_build_tiled(sph_ctx *c);
 constexpr int WT_TILE_RECORDS = 3712;     // whole-tile kernels: {x,y,z,m} records per LDS tile (116 KB; + the kernel table <= 160 KB)
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc);
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part);
+double forces_lane_efficiency(const std::vector<int32_t> &cnt);   // list entries / lane-trips of the forces kernel in use (host, statistics)
 // self-gravity (gravity.hip)
 hipError_t grav_sort_tmp_bytes(int64_t n, size_t *bytes);
 int gravity_tree_build(sph_ctx *c);

@@ -16,8 +16,10 @@
 // Replaces (citations: /root/reference/SUMMER_SPH.f90, "[F]"): the same reference code as pairs.hip --
 // density_tree_search/get_density [F]:398-457, get_pressure_and_sound_speed [F]:459-468,
 // SPH_tree_search/get_SPH [F]:295-395, zero_rates + gas side of sink_gravforces [F]:779-793,559-576.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 
 #include "pair_common.hpp"
 
@@ -724,6 +726,28 @@ int nlist_build_tiled(sph_ctx *c) {
     return SPH_ERR_STATE;
 }
 
+
+// list entries / lane-trips of the forces kernel in use, for a list with the given lengths (sorted-slot order)
+double forces_lane_efficiency(const std::vector<int32_t> &cnt) {
+    const FwtVariant fv = FWT_VARIANTS[fwt_variant()];
+    double entries = 0.0, lane_trips = 0.0;
+    if (fv.rec == 12) {       // forces_q: groups of 256 dealt by length, waves of 16 targets x 4 lanes, a trip = a row of four
+        std::vector<int32_t> g;
+        for (size_t b = 0; b < cnt.size(); b += 256) {
+            g.assign(cnt.begin() + b, cnt.begin() + std::min(cnt.size(), b + 256));
+            std::sort(g.begin(), g.end(), std::greater<int32_t>());
+            for (size_t w = 0; w < g.size(); w += 16) lane_trips += 64.0 * ((g[w] + 3) / 4);
+            for (int32_t v : g) entries += v;
+        }
+    } else {
+        for (size_t w = 0; w < cnt.size(); w += 64) {
+            int32_t m = 0;
+            for (size_t k = w; k < std::min(cnt.size(), w + 64); k++) { m = std::max(m, cnt[k]); entries += cnt[k]; }
+            lane_trips += 64.0 * m;
+        }
+    }
+    return lane_trips > 0.0 ? entries / lane_trips : 0.0;
+}
 
 // ---- whole-tile kernels -------------------------------------------------------------------------------------
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {

@@ -369,9 +369,9 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
         for (int r = 0; r < nrow; r++) {
             const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int k = 4 * r + v;
-                if (k < kmax) {                                     // wave-uniform
+            for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the pipeline registers rotate by
+                const int k = 4 * r + v;                  // renaming instead of moves (tiled.hip density_wt)
+                {
                     const double4 pj = p1;
                     const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
                     if (k + 1 < cnt) {                              // idle lanes issue no gather, nor do entries that count for forces only
@@ -455,46 +455,48 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     int e1 = 0 < cnt ? qa.x : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
-    for (int k = 0; k < kmax; k++) {
-        if ((k & 3) == 0 && k > 0) {                // next row (wave-uniform): rows are streamed two ahead
-            qa = qb;
-            qb = load_row(mine4 + (size_t)min((k >> 2) + 1, nrow - 1) * 64);
+    for (int r = 0; r < nrow; r++) {                  // whole rows (four entries), rows streamed two ahead
+        const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int k = 4 * r + v;
+            const double4 Aj = A1, Bj = B1, Cj = C1;
+            const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
+            if (k + 1 < cnt) {                          // idle lanes issue no gather
+                e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
+                fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
+                A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
+            }
+            const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
+            const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+            double dr, rs;
+            fast_sqrt_rsqrt(r2, dr, rs);
+            if (act && r2 > 0.0) {
+                const double hj = Cj.w;
+                const double inv_hj = fast_rcp(hj);
+                const double qo = dr * inv_h, qn = dr * inv_hj;
+                const double ihj2 = inv_hj * inv_hj;
+                // dW(r, h_i) and dW(r, h_j), each normalised with its own h ([V]:395-396,140)
+                const double dWo = qo <= 2.0 ? table_lerp(lds_dw, qo, inv_dq, pc.nq) * inv_n4i : 0.0;
+                const double dWn = qn <= 2.0 ? table_lerp(lds_dw, qn, inv_dq, pc.nq) * (ihj2 * ihj2 * inv_pi) : 0.0;
+                const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;               // [V]:387
+                const double vr = v0 * n0 + v1 * n1 + v2 * n2;
+                const double vdotr = fmin(vr, 0.0);                                           // [V]:388-390
+                const double dWs = 0.5 * (dWo + dWn);
+                const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
+                const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
+                const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
+                const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
+                const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
+                const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
+                const double mS = Aj.w * S;
+                s0 = fma(mS, n0, s0); s1 = fma(mS, n1, s1); s2 = fma(mS, n2, s2);             // [V]:416
+                const double mv = Aj.w * vdotgradW;
+                sdu = fma(mv, Cc.z + 0.5 * visc, sdu);                                        // [V]:419-421
+                sdal += mv;                                                                   // [V]:427
+            }
         }
-        const double4 Aj = A1, Bj = B1, Cj = C1;
-        const bool act = k < cnt && ((uint32_t)e1 & FLAG_F);
-        if (k + 1 < cnt) {                          // idle lanes issue no gather
-            e1 = (k & 3) < 3 ? comp4(qa, (k & 3) + 1) : qb.x;
-            fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
-            A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
-        }
-        const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
-        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-        double dr, rs;
-        fast_sqrt_rsqrt(r2, dr, rs);
-        if (act && r2 > 0.0) {
-            const double hj = Cj.w;
-            const double inv_hj = fast_rcp(hj);
-            const double qo = dr * inv_h, qn = dr * inv_hj;
-            const double ihj2 = inv_hj * inv_hj;
-            // dW(r, h_i) and dW(r, h_j), each normalised with its own h ([V]:395-396,140)
-            const double dWo = qo <= 2.0 ? table_lerp(lds_dw, qo, inv_dq, pc.nq) * inv_n4i : 0.0;
-            const double dWn = qn <= 2.0 ? table_lerp(lds_dw, qn, inv_dq, pc.nq) * (ihj2 * ihj2 * inv_pi) : 0.0;
-            const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;               // [V]:387
-            const double vr = v0 * n0 + v1 * n1 + v2 * n2;
-            const double vdotr = fmin(vr, 0.0);                                           // [V]:388-390
-            const double dWs = 0.5 * (dWo + dWn);
-            const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
-            const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
-            const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
-            const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
-            const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
-            const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
-            const double mS = Aj.w * S;
-            s0 = fma(mS, n0, s0); s1 = fma(mS, n1, s1); s2 = fma(mS, n2, s2);             // [V]:416
-            const double mv = Aj.w * vdotgradW;
-            sdu = fma(mv, Cc.z + 0.5 * visc, sdu);                                        // [V]:419-421
-            sdal += mv;                                                                   // [V]:427
-        }
+        qa = qb; qb = qc;
     }
     if (!live) return;
     // zero_rates, [self-gravity], then the gas side of sink_gravforces ([V]:1028-1030, 691-)
