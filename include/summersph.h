@@ -136,7 +136,8 @@ typedef struct sph_stats {
     int64_t device_bytes;   /* HBM held by the context                                    */
     double  nlist_wave_mean;/* mean over wavefronts of the longest list in the wave = trips the pair kernels run */
     int32_t tile_fit_pct_forces; /* as tile_fit_pct, for the forces kernel's workgroup size and tile record            */
-    int32_t reserved0;
+    int32_t host_syncs;     /* stream synchronisations inside grid / list builds since the context was created: a
+                               steady-state fixed-h step adds none (read-backs are taken one build late)       */
     double  lane_efficiency_forces; /* fixed h: list entries / lane-trips of the forces kernel in use (1 = no idle lanes):
                                        forces_q deals targets by list length, so this is not nlist_mean / nlist_wave_mean */
 } sph_stats;

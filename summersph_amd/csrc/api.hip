@@ -307,6 +307,12 @@ int do_update_h(sph_ctx *c) {
 int do_accrete(sph_ctx *c, int64_t *removed) {
     if (!c->order_valid) { c->err = "sph_accrete_and_cull: needs the grid of the current positions (call sph_density first)"; return SPH_ERR_STATE; }
     if (c->n_owned != c->n) { c->err = "sph_accrete_and_cull: not available with ghost particles"; return SPH_ERR_STATE; }
+    if (!c->bbox_exact) {       // the octree's root box is the exact bounding box: take it from the last build's read-back slot
+        API_HIP(hipStreamSynchronize(c->stream));
+        const double *bb = c->h_pinned + 200 + 16 * (1 - c->ring_bbox);
+        for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
+        c->bbox_exact = true;
+    }
     API_TRY(accrete_and_cull(c, removed));
     return sinks_cull(c);                               // Variable.f90:610-613 (after the accretion, like the gas cull)
 }
@@ -472,6 +478,10 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     int st = SPH_OK;
     auto fail = [&](int s) { sph_ctx_destroy(c); return s; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPH_ERR_HIP);
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&c->ev_bbox[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_nl[k], hipEventDisableTiming) != hipSuccess) return fail(SPH_ERR_HIP);
+    c->no_stale = getenv("SPH_SYNC_EVERY_BUILD") != nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 640 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
     std::memset(c->h_pinned, 0, 640 * sizeof(double));
     if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 32, "bbox")) != SPH_OK) return fail(st);
@@ -519,6 +529,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (int k = 0; k < 2; k++) { if (c->ev_bbox[k]) (void)hipEventDestroy(c->ev_bbox[k]); if (c->ev_nl[k]) (void)hipEventDestroy(c->ev_nl[k]); }
     ctx_free(c, c->sel_count); ctx_free_ptr(c, c->sel_tmp); ctx_free(c, c->bnd_boxes);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -558,6 +569,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     API_HIP(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
     c->derived_kept = false;
+    c->ring_bbox_valid = c->ring_nl_valid = false;       // a new particle set: the next build waits for its own read-backs
     return SPH_OK;
 }
 
@@ -663,6 +675,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
     o->nlist_capacity = c->nl_cap; o->nlist_max = c->nl_max;
     o->tile_fit_pct = c->whole_tile ? c->wt_fit_pct : -1;
     o->tile_fit_pct_forces = c->whole_tile ? c->wt_fit_pct_f : -1;
+    o->host_syncs = (int32_t)c->host_syncs;
     o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
     o->density_passes = c->density_passes; o->force_passes = c->force_passes;
     o->device_bytes = c->device_bytes;
@@ -985,7 +998,10 @@ int sph_apply_partials_dev(sph_ctx *c, const double *d_all, int32_t nranks, int3
 int sph_get_bbox(sph_ctx *c, double *lo, double *hi) {
     if (!c || !lo || !hi) return SPH_ERR_ARG;
     if (!c->grid_valid) { c->err = "sph_get_bbox: no grid built for the current positions"; return SPH_ERR_STATE; }
-    for (int a = 0; a < 3; a++) { lo[a] = c->bbox[a]; hi[a] = c->bbox[3 + a]; }
+    DeviceGuard g(c->device);
+    API_HIP(hipStreamSynchronize(c->stream));             // the exact box of the last build sits in its read-back slot
+    const double *bb = c->h_pinned + 200 + 16 * (1 - c->ring_bbox);
+    for (int a = 0; a < 3; a++) { lo[a] = bb[a]; hi[a] = bb[3 + a]; }
     return SPH_OK;
 }
 

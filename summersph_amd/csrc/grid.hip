@@ -365,15 +365,32 @@ int grid_rebuild(sph_ctx *c) {
                                                       c->orig, (int32_t)c->n_owned, c->dead_below, 0);
     bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
     GR_CHECK(hipGetLastError());
-    GR_CHECK(hipMemcpyAsync(c->h_pinned, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    GR_CHECK(hipMemcpyAsync(c->h_pinned + 8, c->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GR_CHECK(hipStreamSynchronize(st));
-    if (*reinterpret_cast<int32_t *>(c->h_pinned + 8) != 0) {
+    // the exact box of the current positions -> read-back slot p.  Who needs it NOW (octree root boxes: variable h,
+    // self-gravity, accretion; the first build of a particle set) waits for it; the plain fixed-h path takes the box of the
+    // previous build, which arrived long ago, widened by one cell: particles outside the grid's box are clamped into its
+    // boundary cells and still meet all their neighbours there, so the box only has to be roughly right.
+    const int p = c->ring_bbox;
+    double *slot = c->h_pinned + 200 + 16 * p;
+    GR_CHECK(hipMemcpyAsync(slot, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    GR_CHECK(hipMemcpyAsync(slot + 6, c->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GR_CHECK(hipEventRecord(c->ev_bbox[p], st));
+    const bool stale = c->ring_bbox_valid && !c->no_stale && !c->variable && !c->gravity && !(c->p.flags & SPH_FLAG_ACCRETE_CULL);
+    const double *bb = slot;
+    if (stale) {
+        GR_CHECK(hipEventSynchronize(c->ev_bbox[1 - p]));
+        bb = c->h_pinned + 200 + 16 * (1 - p);
+    } else {
+        GR_CHECK(hipStreamSynchronize(st));
+        c->host_syncs++;
+    }
+    c->ring_bbox = 1 - p; c->ring_bbox_valid = true; c->bbox_exact = !stale;
+    if (*reinterpret_cast<const int32_t *>(bb + 6) != 0) {
         c->err = "non-finite particle position at grid build";
         return SPH_ERR_NONFINITE;
     }
-    const double *bb = c->h_pinned;
-    for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
+    const double guard = stale ? 2.0 * c->p.h * (1.0 + 1e-6) : 0.0;
+    for (int a = 0; a < 3; a++) { c->bbox[a] = bb[a] - guard; c->bbox[3 + a] = bb[3 + a] + guard; }
+    bb = c->bbox;
     GridDesc g{};
     // fixed h: cells of edge 2h.  variable h: edge 2 <h> with a per-cell maximum of h (varh.hip)
     double edge = 2.0 * (c->variable ? c->h_mean : c->p.h) * (1.0 + 1e-6);

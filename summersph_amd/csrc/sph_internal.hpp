@@ -142,6 +142,16 @@ struct sph_ctx {
     double *bbox_part = nullptr;     // per-block partial min/max
     double *h_pinned = nullptr;      // pinned host scratch (bbox[6], flags, dt, ...)
     int32_t *d_flags = nullptr;      // [0] nonfinite, [1] nlist max count
+    // Read-backs one build stale (no host wait on the step that is being enqueued): the fixed-h path sizes its grid from
+    // the bounding box of the PREVIOUS build plus one cell (a particle outside the box is clamped into a boundary cell and
+    // still finds every neighbour: the box is a matter of speed, not of correctness) and checks the list overflow of the
+    // previous build.  Two pinned slots and two events each, used alternately.
+    hipEvent_t ev_bbox[2] = {nullptr, nullptr}, ev_nl[2] = {nullptr, nullptr};
+    int ring_bbox = 0, ring_nl = 0;
+    bool ring_bbox_valid = false, ring_nl_valid = false;
+    bool bbox_exact = true;          // c->bbox is the exact box of the last build (not the previous one widened)
+    bool no_stale = false;           // SPH_SYNC_EVERY_BUILD: wait for every read-back (A/B switch)
+    int64_t host_syncs = 0;          // stream synchronisations inside the build path (statistics)
 
     // neighbour list: slot k of particle i (wave w = i/64, lane = i%64) lives at
     // nlist[(w*nl_cap + k)*64 + lane]  -> a wave reads 64 consecutive ints per k

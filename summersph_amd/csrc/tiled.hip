@@ -683,49 +683,70 @@ int nlist_build_tiled(sph_ctx *c) {
     const PairConst pc = make_pair_const(c);
     const FwtVariant fv = FWT_VARIANTS[fwt_variant()];
     const unsigned d_blocks = (unsigned)((n + WT_BS - 1) / WT_BS), f_blocks = (unsigned)((n + fv.bs - 1) / fv.bs);
-    if (c->whole_tile) {
-        // how many workgroups of the density / forces geometry fit their tile: flags[4], flags[5]
-        TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, 2 * sizeof(int32_t), c->stream));
-        TL_CHECK(plan_bs(c, WT_BS, tile_cap(pc.nq, 4, true), c->plan_d, c->d_flags + 4));
-        TL_CHECK(plan_bs(c, fv.bs, fv.rec == 12 ? tile_cap_q(pc.nq) : tile_cap(pc.nq, fv.rec, fv.tablds), c->plan_f, c->d_flags + 5));
-        TL_CHECK(hipMemcpyAsync(c->h_pinned + 10, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    auto regrow = [&](int32_t want) {
+        ctx_free(c, c->nlist);
+        c->nl_cap = (want + 3) & ~3;
+        if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
+        return SPH_OK;
+    };
+    // what a build reports: {longest list, misfits of the density geometry, misfits of the forces geometry}
+    auto digest = [&](const int32_t *rep) {
+        c->nl_max = rep[0];
+        if (c->whole_tile) {
+            // the whole-tile kernels pay a prologue and run their fall-back loop at one workgroup per CU: use them when
+            // (nearly) every workgroup's intervals fit the tile -- thin discs and sheets; thick domains keep pairs.hip
+            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)rep[1]) / std::max<int64_t>(d_blocks, 1));
+            c->wt_ok = (int64_t)rep[1] * 10 <= (int64_t)d_blocks;
+            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[2]) / std::max<int64_t>(f_blocks, 1));
+            c->wt_ok_f = (int64_t)rep[2] * 10 <= (int64_t)f_blocks;
+        }
+    };
+    // Steady state: the report of the PREVIOUS build (it arrived long ago) is read instead of waiting for this one's.  The
+    // list keeps a third of headroom, so a list that overflows within one step (which the dt control all but excludes) is
+    // an error reported one build late, not a silent truncation.
+    const bool trusted = c->ring_nl_valid && !c->no_stale;
+    const int p = c->ring_nl;
+    int32_t *slot = reinterpret_cast<int32_t *>(c->h_pinned + 240 + 8 * p);
+    if (trusted) {
+        TL_CHECK(hipEventSynchronize(c->ev_nl[1 - p]));
+        const int32_t *prev = reinterpret_cast<const int32_t *>(c->h_pinned + 240 + 8 * (1 - p));
+        if (prev[0] > c->nl_cap) { c->err = "neighbour list overflowed in the previous build (lists grew by more than a third within one step)"; return SPH_ERR_STATE; }
+        digest(prev);
+        if (4 * (int64_t)prev[0] > 3 * (int64_t)c->nl_cap) { const int st = regrow(prev[0] + prev[0] / 2 + 8); if (st != SPH_OK) return st; }
     }
     for (int attempt = 0; attempt < 8; attempt++) {
+        if (c->whole_tile) {
+            // the tile plans of both geometries; how many workgroups do not fit their tile: flags[4], flags[5]
+            TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, 2 * sizeof(int32_t), c->stream));
+            TL_CHECK(plan_bs(c, WT_BS, tile_cap(pc.nq, 4, true), c->plan_d, c->d_flags + 4));
+            TL_CHECK(plan_bs(c, fv.bs, fv.rec == 12 ? tile_cap_q(pc.nq) : tile_cap(pc.nq, fv.rec, fv.tablds), c->plan_f, c->d_flags + 5));
+        }
         TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_tiled<<<dim3(tb_blocks(n)), dim3(TB), 0, c->stream>>>(c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start,
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
                                                                     c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned);
         TL_CHECK(hipGetLastError());
-        TL_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (c->whole_tile && fv.rec == 12) {
+            deal_kernel<256><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
+                                                                                              reinterpret_cast<int2 *>(c->deal));
+            TL_CHECK(hipGetLastError());
+        }
+        TL_CHECK(hipMemcpyAsync(slot, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        TL_CHECK(hipMemcpyAsync(slot + 1, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        TL_CHECK(hipEventRecord(c->ev_nl[p], c->stream));
+        if (trusted) break;
         TL_CHECK(hipStreamSynchronize(c->stream));
-        const int32_t mx = *reinterpret_cast<int32_t *>(c->h_pinned + 9);
-        c->nl_max = mx;
-        if (c->whole_tile) {
-            // the whole-tile kernels pay a prologue and run their fall-back loop at one workgroup per CU: use them when
-            // (nearly) every workgroup's intervals fit the tile -- thin discs and sheets; thick domains keep pairs.hip
-            const int32_t *mis = reinterpret_cast<int32_t *>(c->h_pinned + 10);
-            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)mis[0]) / std::max<int64_t>(d_blocks, 1));
-            c->wt_ok = (int64_t)mis[0] * 10 <= (int64_t)d_blocks;
-            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)mis[1]) / std::max<int64_t>(f_blocks, 1));
-            c->wt_ok_f = (int64_t)mis[1] * 10 <= (int64_t)f_blocks;
-        }
-        if (mx <= c->nl_cap) {
-            if (c->whole_tile && fv.rec == 12) {
-                deal_kernel<256><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
-                                                                                                  reinterpret_cast<int2 *>(c->deal));
-                TL_CHECK(hipGetLastError());
-            }
-            c->nlist_builds++;
-            return SPH_OK;
-        }
-        ctx_free(c, c->nlist);
-        c->nl_cap = ((mx + mx / 8 + 8) + 3) & ~3;
-        if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
+        c->host_syncs++;
+        digest(slot);
+        const int32_t mx = slot[0];
+        if (4 * (int64_t)mx <= 3 * (int64_t)c->nl_cap) break;            // fits, with the headroom the steady state relies on
+        if (attempt == 7) { c->err = "neighbour list did not converge"; return SPH_ERR_STATE; }
+        { const int st = regrow(mx + mx / 2 + 8); if (st != SPH_OK) return st; }
     }
-    c->err = "neighbour list did not converge";
-    return SPH_ERR_STATE;
+    c->ring_nl = 1 - p; c->ring_nl_valid = true;
+    c->nlist_builds++;
+    return SPH_OK;
 }
-
 
 // list entries / lane-trips of the forces kernel in use, for a list with the given lengths (sorted-slot order)
 double forces_lane_efficiency(const std::vector<int32_t> &cnt) {

@@ -51,7 +51,7 @@ module sph_hip_binding
     real(c_double) :: nlist_mean
     integer(c_int64_t) :: grid_builds, nlist_builds, density_passes, force_passes, device_bytes
     real(c_double) :: nlist_wave_mean
-    integer(c_int32_t) :: tile_fit_pct_forces, reserved0
+    integer(c_int32_t) :: tile_fit_pct_forces, host_syncs
     real(c_double) :: lane_efficiency_forces
   end type sph_stats
 

@@ -286,3 +286,40 @@ def test_north_star_acceptance_numbers(capi):
     assert abs((e_mine - e0) - (e_ref - e0)) <= 1e-7 * abs(e_ref - e0)      # the drift itself, to 7 digits
     assert rel_err(ctx.field("x"), g["sph_s40_x"]) <= 1e-9
     ctx.close()
+
+
+def test_steady_state_steps_do_not_wait_for_the_device(capi):
+    """the fixed-h step enqueues without host round trips: the grid is sized from the previous build's bounding box (one
+    cell wider; particles outside a box are clamped into its boundary cells and still meet every neighbour) and the list
+    report of the previous build is checked -- and the results are those of a run that waits for every read-back"""
+    import os
+    import subprocess
+    import sys
+    rows = ic.keplerian_disc(60_000, seed=23, nngb=85.0)
+    gas, sinks = ic.split_rows(rows)
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = ctx.run(2, 1e-2, 0.0)
+    before = ctx.stats().host_syncs
+    dt, t = ctx.run(10, dt, t)
+    assert ctx.stats().host_syncs == before
+    mine = {f: ctx.field(f) for f in "x y z vx vy vz u alpha".split()}
+    lo, hi = ctx.bbox()
+    assert lo[0] == mine["x"].min() and hi[1] == mine["y"].max()          # sph_get_bbox still reports the exact box
+    ctx.close()
+    # the same run with SPH_SYNC_EVERY_BUILD=1 (read once per process): same trajectory up to summation order
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np\n" f"sys.path.insert(0, {root!r})\n" "from summersph_amd import capi, ic\n"
+            "gas, sinks = ic.split_rows(ic.keplerian_disc(60_000, seed=23, nngb=85.0))\n"
+            "ctx = capi.Context(device=0); ctx.upload(gas); ctx.set_sinks(sinks)\n"
+            "dt, t = ctx.run(2, 1e-2, 0.0); dt, t = ctx.run(10, dt, t)\n"
+            "assert ctx.stats().host_syncs >= 20\n"
+            "np.savez(sys.argv[1], dt=dt, **{f: ctx.field(f) for f in 'x y z vx vy vz u alpha'.split()})\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sync.npz")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, "SPH_SYNC_EVERY_BUILD": "1"}, timeout=300)
+        ref = dict(np.load(path))
+    assert float(ref["dt"]) == dt
+    for f in mine:
+        assert rel_err(mine[f], ref[f]) <= 1e-12, f
