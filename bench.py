@@ -393,6 +393,24 @@ def main():
                                                       "gravity_ms_per_step": gkt["gravity"][0] / fsteps, "final_dt": gdt,
                                                       "note": "SPH_FLAG_REUSE_GRAVITY: one tree walk per step instead of two, same results bit for bit"}
             gctx.close()
+            # two side records that show the kernel selection away from the friendly geometry: a dense disc (the survey's
+            # anchor: ~200 neighbours) and a thick 3-D box (nothing fits a tile: the direct-gather kernels of pairs.hip)
+            out["side_records"] = {}
+            for tag, n_s, rows_fn in (("dense_disc_200k", 200_000, lambda: ic.keplerian_disc(200_000, seed=212, nngb=340.0)),
+                                      ("thick_box_300k", 300_000, lambda: ic.uniform_box(300_000, seed=213))):
+                g_s, s_s = ic.split_rows(rows_fn())
+                sctx = capi.Context(device=local_rank)
+                sctx.upload(g_s); sctx.set_sinks(s_s)
+                sel, sdt = timed_run(sctx, torch, max(2, args.steps // 2), 1)
+                sst = sctx.stats()
+                skt = {k: sctx.timing_get(k) for k in capi.KERNELS}
+                ss = max(2, args.steps // 2)
+                out["side_records"][tag] = {"value": n_s * ss / sel, "unit": "particle-steps/s", "ms_per_step": sel / ss * 1e3, "n": n_s,
+                                            "mean_neighbours": sst.nlist_mean, "mean_wave_trips": sst.nlist_wave_mean,
+                                            "tile_fit_pct": sst.tile_fit_pct, "tile_fit_pct_forces": sst.tile_fit_pct_forces,
+                                            "lane_efficiency_forces": sst.lane_efficiency_forces,
+                                            "kernel_ms_per_step": {k: v[0] / ss for k, v in skt.items() if v[0] > 0}}
+                sctx.close()
             if not args.reuse_density:
                 # the start-of-step density pass recomputes a bitwise identical rho (positions, masses, h unchanged
                 # since the end of the last step): SPH_FLAG_REUSE_DENSITY keeps it.  Reported beside the headline,

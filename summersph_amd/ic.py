@@ -172,3 +172,18 @@ def _split_rows_fixed(rows: np.ndarray, sink_radius: float = 3.5):
         sinks = {"x": z1.copy(), "y": z1.copy(), "z": z1.copy(), "vx": z1.copy(), "vy": z1.copy(),
                  "vz": z1.copy(), "m": z1.copy(), "radius": z1.copy()}
     return gas, sinks
+
+
+def uniform_box(n: int, seed: int = 213, nngb: float = 50.0, h: float = H_REF, u0: float = 0.25, m_total: float = 0.01,
+                v_sigma: float = 0.05) -> np.ndarray:
+    """Uniform random cube with ~nngb neighbours inside 2h, no sink row: a THICK domain (the candidate intervals of a
+    run of consecutive particles span whole columns, nothing fits an LDS tile) for the bench's side record and the tests."""
+    rng = np.random.default_rng(seed)
+    dens = nngb / (4.0 / 3.0 * np.pi * (2.0 * h) ** 3)
+    edge = (n / dens) ** (1.0 / 3.0)
+    out = np.zeros((n, 8))
+    out[:, 0:3] = rng.uniform(0.0, edge, (n, 3))
+    out[:, 3:6] = rng.normal(0.0, v_sigma, (n, 3))
+    out[:, 6] = u0
+    out[:, 7] = m_total / n
+    return out

@@ -19,6 +19,9 @@ Fixtures written (numpy .npz, float64, no pickles):
   acc2000_traj.npz      simulate() as it is, 3 steps: 3 particles accreted, 3 culled... (full variant)
   bin2000_eval/_traj    circumbinary disc, TWO sinks (sink-sink forces, two accretors): one evaluation, and the
                         full loop for 3 steps
+  ring3000_traj.npz     thin ring r ~ N(r0, 0.05 r0) (BASELINE configs[3] shape) with a velocity dispersion: step 8
+                        (sph variant; state, rho, du); the viscosity switch alpha grows from 0 and the viscous terms act from step 2 on
+                        (`python tests/golden/make_golden.py ring` writes this one only)
 "eval" files hold both the `sph_*` rates (zero_rates + sink_gravforces + get_SPH, i.e.
 find_forces without Barnes-Hut gas self-gravity) and the `full_*` rates (find_forces as is).
 """
@@ -92,7 +95,22 @@ def binary_fixture(td):
              **{"sph_" + k: v for k, v in t_s.items()})
 
 
+def ring_fixture(td):
+    ring = ic.thin_ring(3000, seed=404)
+    rng = np.random.default_rng(405)
+    ring[:-1, 3:6] += rng.normal(0.0, 0.3, (3000, 3))           # converging and diverging pairs: alpha sources, viscous heating
+    p = os.path.join(td, "ring.txt"); txtio.write_ic(p, ring)
+    t_r = keep_steps(run("traj", p, 8, "sph"), {8})
+    keep = {k: v for k, v in t_r.items() if k in ("dt_seq", "n_seq") or k.split("_", 1)[1] in
+            ("x", "y", "z", "vx", "vy", "vz", "u", "alpha", "rho", "du", "sx", "svx", "sm")}
+    np.savez_compressed(os.path.join(HERE, "ring3000_traj.npz"), ic=ring, **{"sph_" + k: v for k, v in keep.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ring":
+        with tempfile.TemporaryDirectory() as td:
+            ring_fixture(td)
+        return
     if not os.path.exists(DRIVER):
         sys.exit("oracle/_ref/ref_driver missing: run oracle/build_ref.sh first (build container only)")
     with tempfile.TemporaryDirectory() as td:
@@ -140,6 +158,7 @@ def main():
         t_a = keep_steps(run("traj", p, 3, "full"), {1, 2, 3})
         np.savez(os.path.join(HERE, "acc2000_traj.npz"), ic=acc, **{"full_" + k: v for k, v in t_a.items()})
         binary_fixture(td)
+        ring_fixture(td)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):
             print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")

@@ -323,3 +323,37 @@ def test_steady_state_steps_do_not_wait_for_the_device(capi):
     assert float(ref["dt"]) == dt
     for f in mine:
         assert rel_err(mine[f], ref[f]) <= 1e-12, f
+
+
+def test_viscous_ring_trajectory_and_per_element_density(capi):
+    """thin ring with a velocity dispersion (BASELINE configs[3]'s shape), 8 steps of the real reference: identical dt
+    decisions, state <= 1e-10 of each field's scale, and the density of EVERY particle within 1e-11 of its own value"""
+    g = load_golden("ring3000_traj")
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    dts, t = [1e-2], 0.0
+    for _ in range(8):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt)
+    assert dts == list(g["sph_dt_seq"])
+    for f in "x y z vx vy vz u alpha".split():
+        assert rel_err(ctx.field(f), g["sph_s8_" + f]) <= 1e-10, f
+    rho = ctx.field("rho")
+    assert np.all(rho > 0.0)
+    assert float(np.max(np.abs(rho - g["sph_s8_rho"]) / g["sph_s8_rho"])) <= 1e-11
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["sod1000_eval", "disc3000_eval", "bin2000_eval"])
+def test_single_evaluation_per_element(capi, name):
+    """relative to each element, not to the field's maximum: rho of every particle (strictly positive), and |a| of every
+    particle whose acceleration is not a cancellation residue"""
+    g = load_golden(name)
+    ctx, gas, sinks = make_ctx(capi, g["ic"])
+    ctx.density(); ctx.forces()
+    rho = ctx.field("rho")
+    assert float(np.max(np.abs(rho - g["rho"]) / g["rho"])) <= 1e-13
+    a = np.sqrt(ctx.field("ax") ** 2 + ctx.field("ay") ** 2 + ctx.field("az") ** 2)
+    aref = np.sqrt(g["sph_ax"] ** 2 + g["sph_ay"] ** 2 + g["sph_az"] ** 2)
+    big = aref > 1e-3 * np.max(aref)
+    assert float(np.max(np.abs(a[big] - aref[big]) / aref[big])) <= 1e-11
+    ctx.close()
