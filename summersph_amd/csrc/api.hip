@@ -484,7 +484,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     c->no_stale = getenv("SPH_SYNC_EVERY_BUILD") != nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), 640 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(SPH_ERR_NOMEM);
     std::memset(c->h_pinned, 0, 640 * sizeof(double));
-    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 6 + 32, "bbox")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 8 + 64, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 8, "flags")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);

@@ -87,6 +87,47 @@ __global__ __launch_bounds__(384) void bbox_final(const double *__restrict__ par
     if (lane == 0) out[comp] = r;
 }
 
+// count, sum and sum of squares per axis of the live particles inside box (lo, hi): partial[b*7 + ...].  For the trimmed
+// grid box of very sparse domains (grid_rebuild); two stages with a fixed order, like the bounding box.
+struct Box6 { double lo[3], hi[3]; };
+__global__ __launch_bounds__(BB_BLOCK) void moment_partial(const double *__restrict__ x, const double *__restrict__ y,
+                                                           const double *__restrict__ z, int64_t n, Box6 box,
+                                                           double *__restrict__ partial, const int32_t *__restrict__ orig,
+                                                           int32_t n_owned, int64_t dead_below) {
+    __shared__ double sm[7][BB_BLOCK / WAVE];
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * BB_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BB_BLOCK) {
+        if (i < dead_below && orig[i] >= n_owned) continue;
+        const double v[3] = {x[i], y[i], z[i]};
+        const bool in = v[0] >= box.lo[0] && v[0] <= box.hi[0] && v[1] >= box.lo[1] && v[1] <= box.hi[1] && v[2] >= box.lo[2] && v[2] <= box.hi[2];
+        if (!in) continue;
+        acc[0] += 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { acc[1 + a] += v[a]; acc[4 + a] += v[a] * v[a]; }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        double r = acc[k];
+        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0) sm[k][wv] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double r = 0.0;
+        for (int k = 0; k < BB_BLOCK / WAVE; k++) r += sm[threadIdx.x][k];
+        partial[(int64_t)blockIdx.x * 7 + threadIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(448) void moment_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+    const int comp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double r = 0.0;
+    for (int b = lane; b < nblocks; b += 64) r += partial[b * 7 + comp];
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+    if (lane == 0) out[comp] = r;
+}
+
 __device__ __forceinline__ uint32_t cell_key(const GridDesc &g, double px, double py, double pz, int cc[3]) {
     const double p[3] = {px, py, pz};
     int c[3];
@@ -401,6 +442,45 @@ int grid_rebuild(sph_ctx *c) {
         if (vol > 134217728.0) edge *= std::cbrt(vol / 134217728.0);
     }
     g.inv_edge = 1.0 / edge;
+    // Very sparse domains (a particle that escaped to 1e5 AU, a diffuse halo): the cell table must not grow with the
+    // VOLUME of the bounding box.  The grid's box need not hold every particle -- a particle outside it is clamped into
+    // a boundary cell, where it still meets all its neighbours (cells are >= 2h wide, so everything within 2h of an
+    // outside particle is clamped to the same layer or sits in the last one) -- so when the exact box would need more
+    // than ~64 cells per particle the grid covers the bulk only: mean +- 6 sigma of the particles inside the current box,
+    // trimmed repeatedly (a far outlier inflates sigma, the next round no longer sees it).  Results do not depend on the
+    // box beyond summation order; only the boundary cells get crowded if MANY particles lie outside.
+    double tb[6] = {bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]};
+    auto cells_of = [&](const double *b) {
+        double v = 1.0;
+        for (int a = 0; a < 3; a++) v *= std::floor((b[3 + a] - b[a]) * g.inv_edge) + 1.0;
+        return v;
+    };
+    const double sparse_limit = 64.0 * (double)ns + 4.0e6;
+    for (int round = 0; round < 8 && cells_of(tb) > sparse_limit; round++) {
+        Box6 bx;
+        for (int a = 0; a < 3; a++) { bx.lo[a] = tb[a]; bx.hi[a] = tb[3 + a]; }
+        double *mpart = c->bbox_part;                                   // >= 1024 * 7 doubles
+        moment_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, bx, mpart, c->orig,
+                                                            (int32_t)c->n_owned, c->dead_below);
+        moment_final<<<dim3(1), dim3(448), 0, st>>>(mpart, nb, mpart + (size_t)BB_MAX_BLOCKS * 7);
+        GR_CHECK(hipGetLastError());
+        GR_CHECK(hipMemcpyAsync(c->h_pinned + 280, mpart + (size_t)BB_MAX_BLOCKS * 7, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+        GR_CHECK(hipStreamSynchronize(st));
+        c->host_syncs++;
+        const double *mo = c->h_pinned + 280;
+        if (!(mo[0] >= 1.0)) break;
+        bool shrunk = false;
+        for (int a = 0; a < 3; a++) {
+            const double mean = mo[1 + a] / mo[0];
+            const double sig = std::sqrt(std::max(mo[4 + a] / mo[0] - mean * mean, 0.0));
+            const double half = 6.0 * sig + 2.0 * edge;
+            const double lo = std::max(tb[a], mean - half), hi = std::min(tb[3 + a], mean + half);
+            if (lo > tb[a] || hi < tb[3 + a]) shrunk = true;
+            tb[a] = lo; tb[3 + a] = hi;
+        }
+        if (!shrunk) break;
+    }
+    bb = tb;
     double ncell_d = 1.0;
     for (int a = 0; a < 3; a++) {
         g.org[a] = bb[a];

@@ -357,3 +357,43 @@ def test_single_evaluation_per_element(capi, name):
     big = aref > 1e-3 * np.max(aref)
     assert float(np.max(np.abs(a[big] - aref[big]) / aref[big])) <= 1e-11
     ctx.close()
+
+
+def test_far_outlier_costs_a_trimmed_grid_not_an_error(capi):
+    """disc + one particle at 1e5 AU, no cull ('sph' mode): the bounding box would need 1e12 cells.  The grid then covers
+    the bulk only (mean +- 6 sigma, trimmed), the outlier is clamped into a boundary cell and still meets exactly its own
+    neighbours (none).  Every disc particle gets the sums of the disc alone, the outlier m W(0) and its sink gravity."""
+    from oracle import orc
+    g = load_golden("disc3000_eval")
+    gas, sinks = ic.split_rows(g["ic"])
+    n = gas["x"].size
+    far = {k: np.append(v, 0.0) for k, v in gas.items() if isinstance(v, np.ndarray) and v.shape == (n,)}
+    far["x"][n] = 1.0e5; far["y"][n] = -3.0e4; far["z"][n] = 2.0e3
+    far["m"][n] = gas["m"][0]; far["u"][n] = 0.25
+    far["vx"][n] = 0.1            # (a particle at rest would hold the global time step at its floor: |v| / |a| = 0, [F]:844)
+    ctx = capi.Context(device=0)
+    ctx.upload(far); ctx.set_sinks(sinks)
+    ctx.density(); ctx.forces()
+    st = ctx.stats()
+    assert st.n_cells < 64 * (n + 1) + 4_100_000
+    o = orc.Oracle(gas, sinks)
+    o.evaluate()
+    for f in ("rho", "P", "c", "ax", "ay", "az", "du", "dalpha"):
+        assert rel_err(ctx.field(f)[:n], getattr(o, f)) <= EVAL_TOL, f
+    assert ctx.field("rho")[n] == pytest.approx(far["m"][n] / (3.14159265359 * 2.5 ** 3), rel=1e-15)
+    assert ctx.field("du")[n] == 0.0
+    d = np.array([far["x"][n] - sinks["x"][0], far["y"][n] - sinks["y"][0], far["z"][n] - sinks["z"][0]])
+    a_sink = -sinks["m"][0] * ctx.params.G * d / np.sqrt((d ** 2).sum()) ** 3
+    got = np.array([ctx.field("ax")[n], ctx.field("ay")[n], ctx.field("az")[n]])
+    assert np.max(np.abs(got - a_sink)) <= 1e-14 * np.max(np.abs(a_sink))
+    # and it keeps stepping: five steps, the disc follows the reference's trajectory (the outlier does not touch it;
+    # its pull on the sink is 1e-13 of the disc's)
+    gt = load_golden("disc3000_traj")
+    dts, t = [1e-2], 0.0
+    for _ in range(5):
+        dt, t = ctx.step(dts[-1], t)
+        dts.append(dt)
+    assert dts == list(gt["sph_dt_seq"])
+    for f in "x y z vx vy vz u alpha".split():
+        assert rel_err(ctx.field(f)[:n], gt["sph_s5_" + f]) <= 1e-10, f
+    ctx.close()
