@@ -22,6 +22,7 @@
 #include <functional>
 
 #include "pair_common.hpp"
+#include "tile_common.hpp"
 
 namespace sph {
 
@@ -141,19 +142,6 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
 // the LDS loop (the compiler then waits for vmcnt(0) before every use); list rows fetched with wave-uniform,
 // unconditional loads and a scalar trip count; enough waves per SIMD.
 // ------------------------------------------------------------------------------------------
-struct TileMap {
-    int lo[3], len[3], base[3];
-    int need;             // records of the three intervals together
-    // branch-free: the third interval is the default (every list entry of a workgroup whose tile fits lies in one of the three)
-    __device__ __forceinline__ int slot(int j) const {
-        const unsigned u0 = (unsigned)(j - lo[0]), u1 = (unsigned)(j - lo[1]);
-        int s = base[2] + (j - lo[2]);
-        s = u1 < (unsigned)len[1] ? base[1] + (int)u1 : s;
-        s = u0 < (unsigned)len[0] ? (int)u0 : s;
-        return s;
-    }
-};
-
 // s_lo / s_hi: LDS scratch of 3 * NW ints each (NW = waves per workgroup); one barrier for the three intervals
 template <int NW>
 __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__restrict__ cell_start, const int cc[3], bool live,
@@ -188,38 +176,7 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
     m.need = total;
 }
 
-__device__ __forceinline__ void load_plan(const int32_t *__restrict__ plan, int64_t group, TileMap &tm) {
-    const int32_t *p = plan + 8 * (size_t)group;
-    const int4 a = *reinterpret_cast<const int4 *>(p), b = *reinterpret_cast<const int4 *>(p + 4);      // two 16-byte loads
-    tm.lo[0] = a.x; tm.lo[1] = a.y; tm.lo[2] = a.z; tm.len[0] = a.w; tm.len[1] = b.x; tm.len[2] = b.y;
-    tm.base[0] = 0; tm.base[1] = a.w; tm.base[2] = a.w + b.x;
-    tm.need = b.z;
-}
-
 __device__ __forceinline__ size_t poff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
-
-// Staging: the three intervals form one index space, tile slot s <- record lo[q] + (s - base[q]); a record is UPR units
-// of 16 bytes; unit t of the tile goes to dst[SWZ ? q_unit(s) + part : t].  U loads in flight per thread: staging is
-// latency-bound (one workgroup per CU, nothing else to run), so what counts is the number of round trips.
-__device__ __forceinline__ int q_unit(int s) { return 6 * s + (s >> 3); }
-template <int BS, int U, int UPR, bool SWZ>
-__device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
-    const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
-    const int count = UPR * tm.need;
-    for (int t0 = threadIdx.x; t0 < count; t0 += U * BS) {
-        double2 v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {                              // unconditional (clamped) loads: plain registers
-            const int t = min(t0 + u * BS, count - 1), sl = t / UPR;
-            v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = t0 + u * BS, sl = t / UPR;
-            if (t < count) dst[SWZ ? q_unit(sl) + (t - UPR * sl) : t] = v[u];
-        }
-    }
-}
 
 template <int BS>
 __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, const int32_t *__restrict__ plan, const double4 *__restrict__ drec,
@@ -676,6 +633,22 @@ hipError_t plan_bs(sph_ctx *c, int bs, int32_t tcap, int32_t *plan, int32_t *mis
             return SPH_ERR_HIP;                                             \
         }                                                                   \
     } while (0)
+
+// ---- shared with varh.hip (tile_common.hpp) -----------------------------------------------------------------------
+hipError_t launch_plan_256(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit) { return plan_launch<256>(c, tcap, plan, misfit); }
+
+hipError_t launch_deal_256(sph_ctx *c) {
+    deal_kernel<256><<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
+                                                                                      reinterpret_cast<int2 *>(c->deal));
+    return hipGetLastError();
+}
+
+// records of `units_per_record` 16-byte units (+ 1 unit per eight records: the bank shift of q_unit) beside a table
+int32_t tile_cap_units(size_t table_bytes, int units_per_record, size_t reserve) {
+    if (table_bytes + reserve + 64 >= (size_t)LDS_BYTES) return 0;
+    const size_t units = ((size_t)LDS_BYTES - reserve - table_bytes) / 16 - 2;
+    return (int32_t)((units * 8) / (size_t)(8 * units_per_record + 1));
+}
 
 int nlist_build_tiled(sph_ctx *c) {
     const int64_t n = c->n;

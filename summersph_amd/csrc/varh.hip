@@ -21,6 +21,8 @@
 // Neighbour search: uniform grid of edge 2 <h> (mean h) with a per-cell maximum of h; a particle
 // scans the cells C with dist(x, C) <= 2 max(h_i, hmax_C), which finds every j with
 // r <= 2 max(h_i, h_j) without making the cells as large as the largest h.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -328,6 +330,88 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     }
 }
 
+
+// ---- the variable-h pair terms, written once (gather kernels and tile kernels call these) ---------------------------
+struct DensSumsV { double s1 = 0.0, s2 = 0.0; };     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
+
+__device__ __forceinline__ void density_visit_v(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lw,
+                                                const double *__restrict__ ldw, double inv_h, double inv_dq, int nq, DensSumsV &d) {
+    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
+    double dr, rs;
+    fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
+    const double qi = dr * inv_h;
+    if (act && qi <= 2.0) {
+        double wl, dwl;
+        table_lerp2(lw, ldw, qi, inv_dq, nq, wl, dwl);                               // [V]:486
+        d.s1 = fma(pj.w, wl, d.s1);                                                  // [V]:492
+        d.s2 = fma(pj.w, qi * dwl - 3.0 * wl, d.s2);                                 // [V]:487,493 (x -pi h^4)
+    }
+}
+
+// rho, Omega, EOS and the force record of particle i from its sums (self term: the walk reaches the body's own leaf, r = 0)
+__device__ __forceinline__ void density_epilogue_v(const PairConst &pc, int64_t i, const double4 &pi, double hi, DensSumsV d, double w0,
+                                                   const double *__restrict__ u, const double *__restrict__ alpha,
+                                                   const double *__restrict__ vx, const double *__restrict__ vy,
+                                                   const double *__restrict__ vz, double *__restrict__ rho, double *__restrict__ omega,
+                                                   double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec) {
+    d.s1 = fma(pi.w, w0, d.s1);
+    d.s2 = fma(pi.w, -3.0 * w0, d.s2);
+    const double h3 = hi * hi * hi;
+    const double rhoi = d.s1 / (pc.kernel_pi * h3);                                      // [V]:139
+    const double om_acc = -d.s2 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));             // [V]:140,487
+    const double omi = 1.0 + (hi / (3.0 * rhoi)) * om_acc;                               // [V]:455
+    const double Pi = pc.gamma_m1 * u[i] * rhoi;                                         // [V]:509
+    const double ci = sqrt(pc.gamma * Pi / rhoi);                                        // [V]:510
+    rho[i] = rhoi; omega[i] = omi; P[i] = Pi; cs[i] = ci;
+    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi / (omi * rhoi * rhoi), ci, alpha[i], hi);           // [V]:413
+}
+
+// one visit of the grad-h force sums, [V]:385-427.  A, B, C: the target's record (C.w = h_i); inv_n4i = 1 / (pi h_i^4)
+__device__ __forceinline__ void force_visit_v(const PairConst &pc, double hi, double inv_h, double inv_dq, double inv_pi, double inv_n4i,
+                                              const double *__restrict__ lds_dw, const double4 &A, const double4 &B, const double4 &Cc,
+                                              const double4 &Aj, const double4 &Bj, const double4 &Cj, bool act, ForceSums &f) {
+    const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
+    const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
+    double dr, rs;
+    fast_sqrt_rsqrt(r2, dr, rs);
+    if (act && r2 > 0.0) {
+        const double hj = Cj.w;
+        const double inv_hj = fast_rcp(hj);
+        const double qo = dr * inv_h, qn = dr * inv_hj;
+        const double ihj2 = inv_hj * inv_hj;
+        // dW(r, h_i) and dW(r, h_j), each normalised with its own h ([V]:395-396,140)
+        const double dWo = qo <= 2.0 ? table_lerp(lds_dw, qo, inv_dq, pc.nq) * inv_n4i : 0.0;
+        const double dWn = qn <= 2.0 ? table_lerp(lds_dw, qn, inv_dq, pc.nq) * (ihj2 * ihj2 * inv_pi) : 0.0;
+        const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;               // [V]:387
+        const double vr = v0 * n0 + v1 * n1 + v2 * n2;
+        const double vdotr = fmin(vr, 0.0);                                           // [V]:388-390
+        const double dWs = 0.5 * (dWo + dWn);
+        const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
+        const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
+        const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
+        const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
+        const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
+        const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
+        const double mS = Aj.w * S;
+        f.s0 = fma(mS, n0, f.s0); f.s1 = fma(mS, n1, f.s1); f.s2 = fma(mS, n2, f.s2); // [V]:416
+        const double mv = Aj.w * vdotgradW;
+        f.sdu = fma(mv, Cc.z + 0.5 * visc, f.sdu);                                    // [V]:419-421
+        f.sdal += mv;                                                                 // [V]:427
+    }
+}
+
+// rates of particle i from its sums (variable h): sink gravity, the alpha rate of [V]:346
+__device__ __forceinline__ void force_epilogue_v(const PairConst &pc, const double *__restrict__ sink, int64_t i, const double4 &A,
+                                                 double rho_half, double c_half, double al_half, double hi, const ForceSums &f,
+                                                 double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
+                                                 double *__restrict__ du, double *__restrict__ dalpha) {
+    double a0, a1, a2;
+    sink_gas_accel(pc, sink, A, i, ax, ay, az, a0, a1, a2);      // zero_rates, [self-gravity], sink_gravforces ([V]:1028-1030, 691-)
+    ax[i] = a0 - f.s0; ay[i] = a1 - f.s1; az[i] = a2 - f.s2;
+    du[i] = f.sdu;
+    dalpha[i] = fmax(f.sdal / (2.0 * rho_half), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * al_half) * (2.0 * c_half) / hi);
+}
+
 // ---- density + Omega + EOS ---------------------------------------------------------------------------
 __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const double4 *__restrict__ drec,
                                                            const int32_t *__restrict__ nlist, int32_t cap,
@@ -359,7 +443,7 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
 
     // list rows as int4 (four entries), streamed two rows ahead with wave-uniform loads: a quarter of the list
     // instructions of a per-entry read, and the rows do not displace the gather records from the caches
-    double s1 = 0.0, s2 = 0.0;     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
+    DensSumsV d;
     if (kmax > 0) {
         const int nrow = (kmax + 3) >> 2;
         int4 qa = load_row(mine4);
@@ -369,41 +453,21 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
         for (int r = 0; r < nrow; r++) {
             const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
-            for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the pipeline registers rotate by
-                const int k = 4 * r + v;                  // renaming instead of moves (tiled.hip density_wt)
-                {
-                    const double4 pj = p1;
-                    const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
-                    if (k + 1 < cnt) {                              // idle lanes issue no gather, nor do entries that count for forces only
-                        e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
-                        if ((uint32_t)e1 & FLAG_D) p1 = drec[e1 & IDX_MASK];
-                    }
-                    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
-                    double dr, rs;
-                    fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
-                    const double qi = dr * inv_h;
-                    if (act && qi <= 2.0) {
-                        double wl, dwl;
-                        table_lerp2(lw, ldw, qi, inv_dq, pc.nq, wl, dwl);                            // [V]:486
-                        s1 = fma(pj.w, wl, s1);                                                      // [V]:492
-                        s2 = fma(pj.w, qi * dwl - 3.0 * wl, s2);                                     // [V]:487,493 (x -pi h^4)
-                    }
+            for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test (tiled.hip density_wt)
+                const int k = 4 * r + v;
+                const double4 pj = p1;
+                const bool act = k < cnt && ((uint32_t)e1 & FLAG_D);
+                if (k + 1 < cnt) {                              // idle lanes issue no gather, nor do entries that count for forces only
+                    e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
+                    if ((uint32_t)e1 & FLAG_D) p1 = drec[e1 & IDX_MASK];
                 }
+                density_visit_v(pi, pj, act, lw, ldw, inv_h, inv_dq, pc.nq, d);
             }
             qa = qb; qb = qc;
         }
     }
     if (!live) return;
-    s1 = fma(pi.w, lw[0], s1);                       // self: the walk reaches the body's own leaf, r = 0
-    s2 = fma(pi.w, -3.0 * lw[0], s2);
-    const double h3 = hi * hi * hi;
-    const double rhoi = s1 / (pc.kernel_pi * h3);                                        // [V]:139
-    const double om_acc = -s2 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));               // [V]:140,487
-    const double omi = 1.0 + (hi / (3.0 * rhoi)) * om_acc;                               // [V]:455
-    const double Pi = pc.gamma_m1 * u[i] * rhoi;                                         // [V]:509
-    const double ci = sqrt(pc.gamma * Pi / rhoi);                                        // [V]:510
-    rho[i] = rhoi; omega[i] = omi; P[i] = Pi; cs[i] = ci;
-    write_frec(frec, i, pi, vx[i], vy[i], vz[i], rhoi, Pi / (omi * rhoi * rhoi), ci, alpha[i], hi);           // [V]:413
+    density_epilogue_v(pc, i, pi, hi, d, lw[0], u, alpha, vx, vy, vz, rho, omega, P, cs, frec);
 }
 
 __global__ __launch_bounds__(256) void eos_only_v_kernel(PairConst pc, int64_t n, const double4 *__restrict__ drec,
@@ -448,7 +512,7 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq, inv_pi = 1.0 / pc.kernel_pi;
     const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
 
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sdu = 0.0, sdal = 0.0;
+    ForceSums f;
     const int nrow = (kmax + 3) >> 2;
     int4 qa = make_int4(0, 0, 0, 0), qb = qa;
     if (kmax > 0) { qa = load_row(mine4); qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64); }
@@ -467,46 +531,14 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
                 fj = reinterpret_cast<const double4 *>(frec + (size_t)(e1 & IDX_MASK) * FREC);
                 A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
             }
-            const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
-            const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-            double dr, rs;
-            fast_sqrt_rsqrt(r2, dr, rs);
-            if (act && r2 > 0.0) {
-                const double hj = Cj.w;
-                const double inv_hj = fast_rcp(hj);
-                const double qo = dr * inv_h, qn = dr * inv_hj;
-                const double ihj2 = inv_hj * inv_hj;
-                // dW(r, h_i) and dW(r, h_j), each normalised with its own h ([V]:395-396,140)
-                const double dWo = qo <= 2.0 ? table_lerp(lds_dw, qo, inv_dq, pc.nq) * inv_n4i : 0.0;
-                const double dWn = qn <= 2.0 ? table_lerp(lds_dw, qn, inv_dq, pc.nq) * (ihj2 * ihj2 * inv_pi) : 0.0;
-                const double v0 = B.x - Bj.x, v1 = B.y - Bj.y, v2 = B.z - Bj.z;               // [V]:387
-                const double vr = v0 * n0 + v1 * n1 + v2 * n2;
-                const double vdotr = fmin(vr, 0.0);                                           // [V]:388-390
-                const double dWs = 0.5 * (dWo + dWn);
-                const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
-                const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
-                const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
-                const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
-                const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
-                const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
-                const double mS = Aj.w * S;
-                s0 = fma(mS, n0, s0); s1 = fma(mS, n1, s1); s2 = fma(mS, n2, s2);             // [V]:416
-                const double mv = Aj.w * vdotgradW;
-                sdu = fma(mv, Cc.z + 0.5 * visc, sdu);                                        // [V]:419-421
-                sdal += mv;                                                                   // [V]:427
-            }
+            force_visit_v(pc, hi, inv_h, inv_dq, inv_pi, inv_n4i, lds_dw, A, B, Cc, Aj, Bj, Cj, act, f);
         }
         qa = qb; qb = qc;
     }
     if (!live) return;
-    // zero_rates, [self-gravity], then the gas side of sink_gravforces ([V]:1028-1030, 691-)
-    double a0, a1, a2;
-    sink_gas_accel(pc, sink, A, i, ax, ay, az, a0, a1, a2);
-    ax[i] = a0 - s0; ay[i] = a1 - s1; az[i] = a2 - s2;
-    du[i] = sdu;
-    // [V]:346
-    dalpha[i] = fmax(sdal / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * Cc.y) * (2.0 * Cc.x) / hi);
+    force_epilogue_v(pc, sink, i, A, B.w, Cc.x, Cc.y, hi, f, ax, ay, az, du, dalpha);
 }
+
 
 // ---- calc_smoothing -------------------------------------------------------------------------------------
 // rho and Omega of ONE body with trial length hn on the tree of the last evaluation (leaf boxes and
