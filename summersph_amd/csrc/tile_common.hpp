@@ -1,5 +1,5 @@
-// tile_common.hpp -- what the whole-tile kernels of the fixed-h path (tiled.hip) and of the variable-h path (varh.hip)
-// share: the three candidate intervals of a group of consecutive targets, their plan in memory, the staging loop.
+// tile_common.hpp -- building blocks of the whole-tile kernels (tiled.hip): the three candidate intervals of a group of
+// consecutive targets, their plan in memory, the staging loop.
 #pragma once
 #include "pair_common.hpp"
 
@@ -58,11 +58,5 @@ __device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, doub
         }
     }
 }
-
-// tile plans (and the dealing order of groups of 256 targets by list length) for the geometry of the persistent
-// four-lanes-per-target kernels: tiled.hip owns the kernels, varh.hip calls them for variable-h contexts too
-hipError_t launch_plan_256(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit);
-hipError_t launch_deal_256(sph_ctx *c);
-int32_t tile_cap_units(size_t table_bytes, int units_per_record, size_t reserve);
 
 }  // namespace sph

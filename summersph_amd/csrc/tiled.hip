@@ -634,22 +634,6 @@ hipError_t plan_bs(sph_ctx *c, int bs, int32_t tcap, int32_t *plan, int32_t *mis
         }                                                                   \
     } while (0)
 
-// ---- shared with varh.hip (tile_common.hpp) -----------------------------------------------------------------------
-hipError_t launch_plan_256(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit) { return plan_launch<256>(c, tcap, plan, misfit); }
-
-hipError_t launch_deal_256(sph_ctx *c) {
-    deal_kernel<256><<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
-                                                                                      reinterpret_cast<int2 *>(c->deal));
-    return hipGetLastError();
-}
-
-// records of `units_per_record` 16-byte units (+ 1 unit per eight records: the bank shift of q_unit) beside a table
-int32_t tile_cap_units(size_t table_bytes, int units_per_record, size_t reserve) {
-    if (table_bytes + reserve + 64 >= (size_t)LDS_BYTES) return 0;
-    const size_t units = ((size_t)LDS_BYTES - reserve - table_bytes) / 16 - 2;
-    return (int32_t)((units * 8) / (size_t)(8 * units_per_record + 1));
-}
-
 int nlist_build_tiled(sph_ctx *c) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
