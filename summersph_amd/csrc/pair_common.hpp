@@ -245,25 +245,4 @@ __device__ __forceinline__ void force_epilogue(const PairConst &pc, const double
     dalpha[i] = fmax((f.sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * C.y) * (2.0 * C.x) / pc.h);
 }
 
-// The dw table entry of knot k, recomputed in registers exactly as the host fills the table (api.hip host_tables,
-// SUMMER_SPH.f90:55-79; same operations, no contraction): lets a kernel give the table's 40 KB of LDS to its tile
-__device__ __forceinline__ double dw_knot(int k, double dq) {
-#pragma clang fp contract(off)
-    // one instruction stream for both branches of the table: s = q, (-3) s + 2.25 (s s)  or  s = 2 - q, 0 s + (-0.75) (s s)
-    // (0 * s + x == x exactly), selected per lane without control flow
-    const double q = (double)k * dq;
-    const bool inner = q <= 1.0;
-    const double sq = inner ? q : 2.0 - q;
-    const double c2 = inner ? 2.25 : -0.75, c1 = inner ? -3.0 : 0.0;
-    const double r = c1 * sq + c2 * (sq * sq);
-    return q <= 2.0 ? r : 0.0;
-}
-__device__ __forceinline__ double dw_lerp_computed(double qi, double inv_dq, double dq, int nq) {
-#pragma clang fp contract(off)
-    const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k;
-    return fma(a, dw_knot(k + 1, dq), (1.0 - a) * dw_knot(k, dq));
-}
-
 }  // namespace sph

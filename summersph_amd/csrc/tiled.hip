@@ -245,138 +245,6 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, con
     density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
 }
 
-// forces.  The tile record holds the first REC of the neighbour's eleven values
-//     x y z m | vx vy vz rho/2 | P/rho^2 | c/2 alpha/2
-// and the rest still comes through the vector-memory path:
-//     REC = 4  {x,y,z,m}: four divergent 16-byte loads per visit remain (v, rho/2 | c/2, alpha/2, P/rho^2);
-//     REC = 9  all but {c/2, alpha/2}: ONE 16-byte load remains;
-//     REC = 11 everything: none.
-// Odd strides also spread a wave's scattered tile reads over all LDS banks.  What fits the 160 KB of a CU beside the
-// 40-KB dw table decides the workgroup size BS (candidates per target: 3.15 at 1024 targets, 3.3 at 512, 3.5 at 384);
-// TABLDS = false gives the table's 40 KB to the tile and recomputes the two table knots of a visit in registers
-// (bitwise the table's values, ~20 more fp64 instructions per visit).  Variants: launch_forces_wt.
-template <int BS, int REC, bool TABLDS>
-__global__ __launch_bounds__(BS) void forces_wt(PairConst pc, int32_t tcap, const int32_t *__restrict__ plan, const double *__restrict__ frec,
-                                                const int32_t *__restrict__ nlist,
-                                                int32_t cap, const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
-                                                const double *__restrict__ dw_tab,
-                                                const double *__restrict__ sink, int64_t n,
-                                                double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
-                                                double *__restrict__ du, double *__restrict__ dalpha,
-                                                const int32_t *__restrict__ orig, int32_t n_owned,
-                                                const int32_t *__restrict__ wave_class, int32_t want) {
-    extern __shared__ double lds_dyn[];
-    double *lds_dw = lds_dyn;
-    double *tile = lds_dyn + (TABLDS ? ((pc.nq + 2) & ~1) : 0);
-    const int64_t group = xcd_chunk(blockIdx.x, gridDim.x);
-    const int64_t i = group * BS + threadIdx.x;
-    if (wave_class) {       // split evaluation (multi-GPU overlap): a block with no wave of class `want` leaves at once
-        bool any = false;
-        const int64_t w0 = (i - threadIdx.x) >> 6;
-        for (int k = 0; k < BS / 64; k++)
-            any |= ((w0 + k) << 6) < n && wave_class[w0 + k] == want;
-        if (!any) return;
-    }
-    const double4 *fg = reinterpret_cast<const double4 *>(frec);
-    TileMap tm;
-    load_plan(plan, group, tm);
-    const bool fits = tm.need <= tcap;
-    if (fits) {
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            for (int t = threadIdx.x; t < tm.len[q]; t += BS) {
-                const double4 *src = fg + (size_t)(tm.lo[q] + t) * 3;
-                double *dst = tile + (size_t)(tm.base[q] + t) * REC;
-                const double4 a = src[0];
-                dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
-                if (REC > 4) {
-                    const double4 b = src[1], c = src[2];
-                    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w; dst[8] = c.z;
-                    if (REC > 9) { dst[9] = c.x; dst[10] = c.y; }
-                }
-            }
-    }
-    if (TABLDS)
-        for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_dw[k] = dw_tab[k];
-    const int lane = threadIdx.x & 63;
-    const int64_t w = i >> 6;
-    const bool live = i < n && orig[i] < n_owned;
-    const int self = i < n ? (int)i : (int)(n - 1);
-    const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
-    __syncthreads();
-    if ((i & ~(int64_t)63) >= n) return;
-    if (wave_class && wave_class[w] != want) return;
-
-    const int cnt = live ? min(ncount[i], cap) : 0;
-    const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    ForceSums f;
-    auto dw_of = [&](double q) { return TABLDS ? table_lerp(lds_dw, q, inv_dq, pc.nq) : dw_lerp_computed(q, inv_dq, pc.dq, pc.nq); };
-    if (fits && kmax > 0) {
-        const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
-        const int nrow = (kmax + 3) >> 2;
-        int4 qa = load_row(mine4);
-        int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
-        int jn = 0 < cnt ? qa.x : self;
-        // the pipeline registers: tile part (T1) and gathered part (G1 / H1) of the NEXT neighbour
-        double T1[REC];
-        double4 G1 = make_double4(0, 0, 0, 0), H1 = make_double4(0, 0, 0, 0);
-        double2 D1 = make_double2(0, 0);
-        {
-            const double *tp = tile + (size_t)(0 < cnt ? tm.slot(jn) : 0) * REC;
-#pragma unroll
-            for (int c = 0; c < REC; c++) T1[c] = tp[c];
-            if (REC == 4) { G1 = fg[(size_t)jn * 3 + 1]; H1 = fg[(size_t)jn * 3 + 2]; }
-            if (REC == 9) D1 = *reinterpret_cast<const double2 *>(frec + (size_t)jn * FREC + 8);
-        }
-        for (int r = 0; r < nrow; r++) {
-            const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int k = 4 * r + v;
-                {                                                   // whole rows, no trip-count test (see density_wt)
-                    Nbr nb;
-                    nb.x = T1[0]; nb.y = T1[1]; nb.z = T1[2]; nb.m = T1[3];
-                    if (REC == 4) {
-                        nb.vx = G1.x; nb.vy = G1.y; nb.vz = G1.z; nb.rho_h = G1.w; nb.c_h = H1.x; nb.al_h = H1.y; nb.P_r2 = H1.z;
-                    } else {
-                        nb.vx = T1[REC > 4 ? 4 : 0]; nb.vy = T1[REC > 4 ? 5 : 0]; nb.vz = T1[REC > 4 ? 6 : 0];
-                        nb.rho_h = T1[REC > 4 ? 7 : 0]; nb.P_r2 = T1[REC > 4 ? 8 : 0];
-                        if (REC == 9) { nb.c_h = D1.x; nb.al_h = D1.y; } else { nb.c_h = T1[REC > 9 ? 9 : 0]; nb.al_h = T1[REC > 9 ? 10 : 0]; }
-                    }
-                    jn = v < 3 ? comp4(qa, v + 1) : qb.x;
-                    const bool more = k + 1 < cnt;
-                    const double *tp = tile + (size_t)(more ? tm.slot(jn) : 0) * REC;
-#pragma unroll
-                    for (int c = 0; c < REC; c++) T1[c] = tp[c];
-                    if (more) {                                     // idle lanes issue no gather
-                        if (REC == 4) { G1 = fg[(size_t)jn * 3 + 1]; H1 = fg[(size_t)jn * 3 + 2]; }
-                        if (REC == 9) D1 = *reinterpret_cast<const double2 *>(frec + (size_t)jn * FREC + 8);
-                    }
-                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
-                }
-            }
-            qa = qb; qb = qc;
-        }
-    } else if (!fits) {
-        const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
-        int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
-        int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
-        const double4 *fj = fg + (size_t)j1 * 3;
-        double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
-        for (int k = 0; k < kmax; k++) {
-            const Nbr nb = nbr_of(A1, B1, C1);
-            j1 = j2;
-            if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
-            if (k + 1 < cnt) { fj = fg + (size_t)j1 * 3; A1 = fj[0]; B1 = fj[1]; C1 = fj[2]; }
-            force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
-        }
-    }
-    if (!live) return;
-    force_epilogue(pc, sink, i, A, B, Cc, f, ax, ay, az, du, dalpha);
-}
-
-
 // forces, LPT lanes per target.  A workgroup of BS threads owns BS / LPT consecutive targets; the LPT lanes of a target take
 // the LPT entries of a list row between them (lane s: component s of every row), so a trip is a row.  Why: (1) the tile of
 // BS / LPT targets is small enough to hold the neighbours' WHOLE 96-byte records beside the dw table -- no vector-memory
@@ -388,7 +256,7 @@ __global__ __launch_bounds__(BS) void forces_wt(PairConst pc, int32_t tcap, cons
 // eight records spreads a wave's scattered 16-byte reads over all banks (6 s mod 16 alone hits the even units only).  The LPT partial sums of a target are added in a fixed tree (lane order), so results are reproducible;
 // they differ from the one-lane kernels' by summation order (parity tolerance, not bitwise).
 
-template <int BS, int LPT, int MODE>
+template <int BS, int LPT>
 __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
                                                const int2 *__restrict__ deal,
                                                const double *__restrict__ frec, const int32_t *__restrict__ nlist,
@@ -451,7 +319,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
         const int cnt = live ? dl.y : 0;
         __syncthreads();
-        const int nrow = MODE >= 4 ? 0 : __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));     // MODE 4: no pair loop (profiling)
+        const int nrow = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));
         ForceSums f;
         // this lane's entries: component `sub` of the rows of target i's list column
         const int32_t *lp = nlist + (((size_t)(self >> 6) * (cap >> 2)) * 64 + (self & 63)) * 4 + sub;
@@ -466,14 +334,11 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                     const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
                     const int k = 4 * r + sub;
                     rp = tile + q_unit(k + 4 < cnt ? tm.slot(eb) : 0);
-                    if (MODE < 3) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5]; }
-                    else { r0.x += 1e-9 * (double)eb; }
+                    r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
                     eb = ec;
                     ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
-                    // MODE: ablations for profiling (tests/tools): 1 = masked body, 2 = + no dw table look-up, 3 = + no tile reads
-                    if (MODE == 0 || MODE == 4) force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
-                    else if (MODE == 1) force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
-                    else force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, [&](double q) { return q * 0.25 - 0.5; }, f);
+                    // the masked form of the pair term (no control flow: consecutive visits overlap; 0.63 -> 0.59 ms per step)
+                    force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
                 }
             } else {
                 int j = sub < cnt ? ea : self;
@@ -563,32 +428,7 @@ __global__ __launch_bounds__(T) void deal_kernel(int64_t n, const int32_t *__res
 
 inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
 
-// ---- the forces kernel in use ---------------------------------------------------------------------------------------
-struct FwtVariant { int bs, rec; bool tablds; };   // bs = targets per workgroup
-// default chosen by measurement on the bench disc; SPH_FWT_VARIANT=<n> selects another for A/B runs
-const FwtVariant FWT_VARIANTS[] = {
-    {1024, 4, true},     // 0: round-1 kernel: {x,y,z,m} tile, 4 gathers
-    {448, 9, true},      // 1: 1 gather, table in LDS
-    {512, 9, false},     // 2: 1 gather, table recomputed
-    {512, 11, false},    // 3: 0 gathers, table recomputed
-    {384, 11, true},     // 4: 0 gathers, table in LDS
-    {384, 9, true},      // 5: 1 gather, table in LDS
-    {256, 11, true},     // 6
-    {768, 9, false},     // 7
-    {256, 12, true},     // 8: forces_q: persistent, 1024 threads, 4 lanes per target, whole records in the tile, table in LDS
-    {256, 12, true}, {256, 12, true}, {256, 12, true}, {256, 12, true},   // 9-12: forces_q ablations (profiling only)
-};
-constexpr int FWT_DEFAULT = 8;
-
-int fwt_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SPH_FWT_VARIANT");
-        v = e ? atoi(e) : FWT_DEFAULT;
-        if (v < 0 || v >= (int)(sizeof(FWT_VARIANTS) / sizeof(FWT_VARIANTS[0]))) v = FWT_DEFAULT;
-    }
-    return v;
-}
+constexpr int FQ_T = 256;            // forces_q: targets per group
 
 int32_t tile_cap(int nq, int rec, bool tablds) {
     const size_t tab = tablds ? (size_t)((nq + 2) & ~1) * sizeof(double) : 0;
@@ -613,14 +453,7 @@ hipError_t plan_launch(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit)
 }
 
 hipError_t plan_bs(sph_ctx *c, int bs, int32_t tcap, int32_t *plan, int32_t *misfit) {
-    switch (bs) {
-        case 1024: return plan_launch<1024>(c, tcap, plan, misfit);
-        case 768: return plan_launch<768>(c, tcap, plan, misfit);
-        case 512: return plan_launch<512>(c, tcap, plan, misfit);
-        case 448: return plan_launch<448>(c, tcap, plan, misfit);
-        case 384: return plan_launch<384>(c, tcap, plan, misfit);
-        default: return plan_launch<256>(c, tcap, plan, misfit);
-    }
+    return bs == 1024 ? plan_launch<1024>(c, tcap, plan, misfit) : plan_launch<256>(c, tcap, plan, misfit);
 }
 
 }  // namespace
@@ -638,8 +471,7 @@ int nlist_build_tiled(sph_ctx *c) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
     const PairConst pc = make_pair_const(c);
-    const FwtVariant fv = FWT_VARIANTS[fwt_variant()];
-    const unsigned d_blocks = (unsigned)((n + WT_BS - 1) / WT_BS), f_blocks = (unsigned)((n + fv.bs - 1) / fv.bs);
+    const unsigned d_blocks = (unsigned)((n + WT_BS - 1) / WT_BS), f_blocks = (unsigned)((n + FQ_T - 1) / FQ_T);
     auto regrow = [&](int32_t want) {
         ctx_free(c, c->nlist);
         c->nl_cap = (want + 3) & ~3;
@@ -676,14 +508,14 @@ int nlist_build_tiled(sph_ctx *c) {
             // the tile plans of both geometries; how many workgroups do not fit their tile: flags[4], flags[5]
             TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, 2 * sizeof(int32_t), c->stream));
             TL_CHECK(plan_bs(c, WT_BS, tile_cap(pc.nq, 4, true), c->plan_d, c->d_flags + 4));
-            TL_CHECK(plan_bs(c, fv.bs, fv.rec == 12 ? tile_cap_q(pc.nq) : tile_cap(pc.nq, fv.rec, fv.tablds), c->plan_f, c->d_flags + 5));
+            TL_CHECK(plan_bs(c, FQ_T, tile_cap_q(pc.nq), c->plan_f, c->d_flags + 5));
         }
         TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_tiled<<<dim3(tb_blocks(n)), dim3(TB), 0, c->stream>>>(c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start,
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
                                                                     c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned);
         TL_CHECK(hipGetLastError());
-        if (c->whole_tile && fv.rec == 12) {
+        if (c->whole_tile) {
             deal_kernel<256><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
                                                                                               reinterpret_cast<int2 *>(c->deal));
             TL_CHECK(hipGetLastError());
@@ -707,22 +539,14 @@ int nlist_build_tiled(sph_ctx *c) {
 
 // list entries / lane-trips of the forces kernel in use, for a list with the given lengths (sorted-slot order)
 double forces_lane_efficiency(const std::vector<int32_t> &cnt) {
-    const FwtVariant fv = FWT_VARIANTS[fwt_variant()];
+    // forces_q: groups of 256 dealt by length, waves of 16 targets x 4 lanes, a trip = a row of four
     double entries = 0.0, lane_trips = 0.0;
-    if (fv.rec == 12) {       // forces_q: groups of 256 dealt by length, waves of 16 targets x 4 lanes, a trip = a row of four
-        std::vector<int32_t> g;
-        for (size_t b = 0; b < cnt.size(); b += 256) {
-            g.assign(cnt.begin() + b, cnt.begin() + std::min(cnt.size(), b + 256));
-            std::sort(g.begin(), g.end(), std::greater<int32_t>());
-            for (size_t w = 0; w < g.size(); w += 16) lane_trips += 64.0 * ((g[w] + 3) / 4);
-            for (int32_t v : g) entries += v;
-        }
-    } else {
-        for (size_t w = 0; w < cnt.size(); w += 64) {
-            int32_t m = 0;
-            for (size_t k = w; k < std::min(cnt.size(), w + 64); k++) { m = std::max(m, cnt[k]); entries += cnt[k]; }
-            lane_trips += 64.0 * m;
-        }
+    std::vector<int32_t> g;
+    for (size_t b = 0; b < cnt.size(); b += 256) {
+        g.assign(cnt.begin() + b, cnt.begin() + std::min(cnt.size(), b + 256));
+        std::sort(g.begin(), g.end(), std::greater<int32_t>());
+        for (size_t w = 0; w < g.size(); w += 16) lane_trips += 64.0 * ((g[w] + 3) / 4);
+        for (int32_t v : g) entries += v;
     }
     return lane_trips > 0.0 ? entries / lane_trips : 0.0;
 }
@@ -741,31 +565,16 @@ hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     return hipGetLastError();
 }
 
-template <int BS, int REC, bool TABLDS>
-static hipError_t forces_wt_launch(sph_ctx *c, const PairConst &pc, int part) {
-    const int32_t tcap = tile_cap(pc.nq, REC, TABLDS);
-    const size_t lds = (TABLDS ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)tcap * REC * sizeof(double);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_wt<BS, REC, TABLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    forces_wt<BS, REC, TABLDS><<<dim3((unsigned)((c->n + BS - 1) / BS)), dim3(BS), lds, c->stream>>>(
-        pc, tcap, c->plan_f, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max,
-        c->dw_tab, c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU],
-        c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned, part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
-    return hipGetLastError();
-}
-
-
-template <int MODE>
 static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     constexpr int BS = 1024, LPT = 4;
     const int32_t tcap = tile_cap_q(pc.nq);
     const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     constexpr int T = BS / LPT;
     const int64_t ngroups = (c->n + T - 1) / T;
     const unsigned grid = (unsigned)std::min<int64_t>(ngroups, std::max(c->num_cus, 8));       // persistent: one workgroup per CU
-    forces_q<BS, LPT, MODE><<<dim3(grid), dim3(BS), lds, c->stream>>>(
+    forces_q<BS, LPT><<<dim3(grid), dim3(BS), lds, c->stream>>>(
         pc, tcap, (int32_t)ngroups, c->plan_f, reinterpret_cast<const int2 *>(c->deal), c->frec, c->nlist, c->nl_cap, c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
         part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
@@ -775,21 +584,7 @@ static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
 // part 0: every wave.  part 1 / 2: only the waves of class 0 (interior) / class 1, as launch_forces
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
-    switch (fwt_variant()) {
-        case 0: return forces_wt_launch<1024, 4, true>(c, pc, part);
-        case 2: return forces_wt_launch<512, 9, false>(c, pc, part);
-        case 3: return forces_wt_launch<512, 11, false>(c, pc, part);
-        case 4: return forces_wt_launch<384, 11, true>(c, pc, part);
-        case 5: return forces_wt_launch<384, 9, true>(c, pc, part);
-        case 6: return forces_wt_launch<256, 11, true>(c, pc, part);
-        case 7: return forces_wt_launch<768, 9, false>(c, pc, part);
-        case 8: return forces_q_launch<0>(c, pc, part);
-        case 9: return forces_q_launch<1>(c, pc, part);
-        case 10: return forces_q_launch<2>(c, pc, part);
-        case 11: return forces_q_launch<3>(c, pc, part);
-        case 12: return forces_q_launch<4>(c, pc, part);
-        default: return forces_wt_launch<448, 9, true>(c, pc, part);
-    }
+    return forces_q_launch(c, pc, part);
 }
 
 }  // namespace sph

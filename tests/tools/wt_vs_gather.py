@@ -1,6 +1,7 @@
-"""one forces_wt variant (SPH_FWT_VARIANT) on the bench disc: a few launches for the counter passes of
-profiles/fwt_counters.sh, and the differences to the direct-gather kernels field by field
-   python tests/tools/fwt_one.py [n] [launches]"""
+"""The whole-tile kernels (density_wt, forces_q) against the direct-gather kernels (SPH_FLAG_NO_WHOLE_TILE) on the bench
+disc: kernel times from the library's own HIP events, and the differences field by field (density bitwise, forces at
+summation-order level).
+   python tests/tools/wt_vs_gather.py [n] [launches]"""
 import os
 import sys
 
