@@ -337,8 +337,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                     r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
                     eb = ec;
                     ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
-                    // the masked form of the pair term (no control flow: consecutive visits overlap; 0.63 -> 0.59 ms per step)
-                    force_visit_masked(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
                 }
             } else {
                 int j = sub < cnt ? ea : self;
