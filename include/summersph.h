@@ -153,6 +153,8 @@ int sph_ctx_destroy(sph_ctx *ctx);
 const char *sph_strerror(int status);
 const char *sph_last_error(const sph_ctx *ctx);
 int sph_abi_version(void);
+/* the parameters the context was created with */
+int sph_get_params(const sph_ctx *ctx, sph_params *out);
 
 /* ---- state hand-over: replaces packing from `type(particle)` / `type(sink)` ([F]:14-37).
  *      alpha may be NULL (-> 0, as the reader initialises it, [F]:681). ------------------ */

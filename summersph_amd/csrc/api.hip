@@ -404,6 +404,12 @@ extern "C" {
 
 int sph_abi_version(void) { return SPH_ABI_VERSION; }
 
+int sph_get_params(const sph_ctx *c, sph_params *out) {
+    if (!c || !out) return SPH_ERR_ARG;
+    *out = c->p;
+    return SPH_OK;
+}
+
 const char *sph_strerror(int s) {
     switch (s) {
         case SPH_OK: return "ok";

@@ -1,0 +1,922 @@
+// halo.hip -- libsummersph_halo.so: the loop body of simulate() on several GPUs without Python (include/summersph_halo.h).
+//
+// A client of the public C ABI (include/summersph.h) only: every physics kernel is the context's; this file owns the
+// orchestration of summersph_amd/dist.py (DistSim._step / evaluate / _exchange_ghosts / _migrate / _reduce, fixed h,
+// no self-gravity) and the two transports it runs on.  Streams: s0 = the context's stream (set with sph_set_stream, so
+// the *_dev calls do not synchronise), s1 = the communication stream.  Every message is packed on s0, an event lets
+// s1 start, the grouped ncclSend / ncclRecv (or the all-gather) runs on s1, a second event lets s0 unpack -- and s0
+// keeps computing between the two events (density, the interior wavefronts of the forces).
+//
+// The reference (/root/reference/SUMMER_SPH.f90:863-930) is one process; the step sequence reproduced is [F]:889-916.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/summersph_halo.h"
+
+namespace {
+
+constexpr int MAXP = 64;                 // sph_select_boxes takes 64 boxes
+constexpr int NF = 9;
+constexpr int DT_SLOT = 192, PRED_SLOT = 193;
+const int32_t STATE[NF] = {SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA};
+
+struct DevGuard {
+    int prev = 0;
+    explicit DevGuard(int d) { (void)hipGetDevice(&prev); (void)hipSetDevice(d); }
+    ~DevGuard() { (void)hipSetDevice(prev); }
+};
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }      // hipFree waits for the device
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- transports -----------------------------------------------------------------------------------------------------
+struct Transport {
+    std::string err;
+    virtual ~Transport() {}
+    // every rank contributes `bytes` from d_send; d_recv gets nranks blocks in rank order
+    virtual int allgather(const void *d_send, void *d_recv, size_t bytes, hipStream_t s) = 0;
+    // one grouped round: sb[q] bytes of d_send[q] to rank q, rb[q] bytes from rank q into d_recv[q] (0 = nothing; q may be
+    // the caller itself)
+    virtual int exchange(const void *const *d_send, const size_t *sb, void *const *d_recv, const size_t *rb, hipStream_t s) = 0;
+};
+
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr;
+    bool own = false;
+    int P = 1;
+    ~RcclTransport() override { if (own && comm) (void)ncclCommDestroy(comm); }
+    int fail(const char *what, ncclResult_t r) { err = std::string(what) + ": " + ncclGetErrorString(r); return SPH_ERR_HIP; }
+    int allgather(const void *d_send, void *d_recv, size_t bytes, hipStream_t s) override {
+        ncclResult_t r = ncclAllGather(d_send, d_recv, bytes, ncclChar, comm, s);
+        return r == ncclSuccess ? SPH_OK : fail("ncclAllGather", r);
+    }
+    int exchange(const void *const *d_send, const size_t *sb, void *const *d_recv, const size_t *rb, hipStream_t s) override {
+        ncclResult_t r = ncclGroupStart();
+        if (r != ncclSuccess) return fail("ncclGroupStart", r);
+        for (int q = 0; q < P; q++) {
+            if (sb[q] > 0) { r = ncclSend(d_send[q], sb[q], ncclChar, q, comm, s); if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail("ncclSend", r); } }
+            if (rb[q] > 0) { r = ncclRecv(d_recv[q], rb[q], ncclChar, q, comm, s); if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail("ncclRecv", r); } }
+        }
+        r = ncclGroupEnd();
+        return r == ncclSuccess ? SPH_OK : fail("ncclGroupEnd", r);
+    }
+};
+
+// the ranks are threads of one process on one device: a message is a device-to-device copy the receiver issues on its own
+// stream once the sender's data is ready (event), and nobody leaves a round before every copy out of its buffers is done
+struct Hub {
+    int P;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    const void *ag[MAXP];
+    const void *const *send[MAXP];
+    const size_t *sb[MAXP];
+    hipEvent_t ready[MAXP], done[MAXP];
+    std::atomic<bool> failed{false};
+    explicit Hub(int p) : P(p) {
+        for (int q = 0; q < MAXP; q++) { ag[q] = nullptr; send[q] = nullptr; sb[q] = nullptr; ready[q] = nullptr; done[q] = nullptr; }
+    }
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        if (++arrived == P) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+struct InprocTransport : Transport {
+    Hub *hub = nullptr;
+    int rank = 0;
+    int finish(hipStream_t s, hipError_t e) {
+        // everybody passes the same barriers whatever happened, so a failing rank cannot strand the others
+        if (e == hipSuccess) e = hipEventRecord(hub->done[rank], s);
+        if (e != hipSuccess) hub->failed = true;
+        hub->barrier();
+        for (int q = 0; q < hub->P && e == hipSuccess; q++) e = hipEventSynchronize(hub->done[q]);
+        hub->barrier();
+        if (e != hipSuccess) { err = std::string("in-process transport: ") + hipGetErrorString(e); return SPH_ERR_HIP; }
+        if (hub->failed) { err = "in-process transport: another rank failed"; return SPH_ERR_STATE; }
+        return SPH_OK;
+    }
+    int allgather(const void *d_send, void *d_recv, size_t bytes, hipStream_t s) override {
+        hipError_t e = hipEventRecord(hub->ready[rank], s);
+        hub->ag[rank] = d_send;
+        hub->barrier();
+        for (int q = 0; q < hub->P && e == hipSuccess; q++) {
+            e = hipStreamWaitEvent(s, hub->ready[q], 0);
+            if (e == hipSuccess && bytes > 0)
+                e = hipMemcpyAsync(static_cast<char *>(d_recv) + (size_t)q * bytes, hub->ag[q], bytes, hipMemcpyDeviceToDevice, s);
+        }
+        return finish(s, e);
+    }
+    int exchange(const void *const *d_send, const size_t *sb, void *const *d_recv, const size_t *rb, hipStream_t s) override {
+        hipError_t e = hipEventRecord(hub->ready[rank], s);
+        hub->send[rank] = d_send;
+        hub->sb[rank] = sb;
+        hub->barrier();
+        bool mismatch = false;
+        for (int q = 0; q < hub->P && e == hipSuccess; q++) {
+            if (hub->sb[q][rank] != rb[q]) { mismatch = true; continue; }
+            if (rb[q] == 0) continue;
+            e = hipStreamWaitEvent(s, hub->ready[q], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_recv[q], hub->send[q][rank], rb[q], hipMemcpyDeviceToDevice, s);
+        }
+        if (mismatch) hub->failed = true;
+        const int st = finish(s, e);
+        if (mismatch) { err = "in-process transport: send and receive sizes differ"; return SPH_ERR_STATE; }
+        return st;
+    }
+};
+
+// ---- small kernels of the orchestration ------------------------------------------------------------------------------
+struct Edges { double e[MAXP]; int n; };
+
+// owner of x: the number of interior edges <= x (torch.bucketize(x, edges, right=True) of dist.py)
+__global__ void dest_kernel(const double *__restrict__ x, int64_t n, Edges ed, int32_t *__restrict__ dest, unsigned long long *__restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double xi = x[i];
+    int d = 0;
+    for (int k = 0; k < ed.n; k++) d += (ed.e[k] <= xi) ? 1 : 0;
+    dest[i] = d;
+    atomicAdd(&counts[d], 1ULL);
+}
+
+__global__ void flag_kernel(const int32_t *__restrict__ dest, int64_t n, int32_t q, uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = dest[i] == q ? 1 : 0;
+}
+
+// dst[r * dst_stride + dst_off + k] = src[r * src_stride + (ids ? ids[k] : k)], r < nrows, k < cnt
+__global__ void gather_rows(const double *__restrict__ src, int64_t src_stride, const int64_t *__restrict__ ids, int64_t cnt, int nrows,
+                            double *__restrict__ dst, int64_t dst_stride, int64_t dst_off) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    const int64_t j = ids ? ids[k] : k;
+    for (int r = 0; r < nrows; r++) dst[(int64_t)r * dst_stride + dst_off + k] = src[(int64_t)r * src_stride + j];
+}
+
+__global__ void gid_to_double(const int64_t *__restrict__ gid, const int64_t *__restrict__ ids, int64_t cnt, double *__restrict__ dst) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) dst[k] = (double)gid[ids ? ids[k] : k];              // global numbers stay below 2^53: exact
+}
+
+__global__ void double_to_gid(const double *__restrict__ src, int64_t cnt, int64_t *__restrict__ dst) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) dst[k] = (int64_t)src[k];
+}
+
+__global__ void gather_gid(const int64_t *__restrict__ gid, const int64_t *__restrict__ ids, int64_t cnt, int64_t *__restrict__ dst) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) dst[k] = gid[ids[k]];
+}
+
+__global__ void iota64(int64_t *p, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = k;
+}
+
+// row = this rank's block with the dt candidate replaced by the minimum over ranks (end of a run, dist.py _finish_dt)
+__global__ void min_dt_row(const double *__restrict__ all, int P, int rank, double *__restrict__ row) {
+    const int k = threadIdx.x;
+    if (k < SPH_PARTIALS) {
+        double v = all[(size_t)rank * SPH_PARTIALS + k];
+        if (k == DT_SLOT) for (int q = 0; q < P; q++) v = fmin(v, all[(size_t)q * SPH_PARTIALS + DT_SLOT]);
+        row[k] = v;
+    }
+}
+
+__global__ void pattern_kernel(double *p, int64_t n, double base) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = base + (double)k;
+}
+
+inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+struct sph_halo {
+    sph_ctx *c = nullptr;
+    int rank = 0, P = 1, device = 0;
+    Transport *tr = nullptr;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    bool own_s1 = true;
+    hipEvent_t e01 = nullptr, e10 = nullptr, e_pred = nullptr;
+    double h = 0.0;
+    Edges edges{};
+    int migrate_every = 32, since_migrate = 0;
+    int64_t n_owned = 0, reserved = 0;
+    bool uploaded = false;
+    bool pos_dirty = true, vel_dirty = false, dt_pending = false, pred_for_drift = false, pred_valid = false;
+    DevBuf gid, gid_new, own, newbuf, part, allpart, row, box, boxes, cnt, cntall, ghosts, dest, flags, keep_ids, sel_tmp, sel_count;
+    DevBuf sendb[MAXP], recvb[MAXP], ids[MAXP];
+    double *pin = nullptr;               // pinned host memory: the gathered partials, the boxes, the count matrix
+    double *pin_part = nullptr, *pin_boxes = nullptr;
+    int64_t *pin_cnt = nullptr, *pin_row = nullptr;
+    int64_t send_count[MAXP], ghost_first[MAXP], ghost_count[MAXP];
+    bool refresh_pending = false;
+    int refresh_nf = 0;
+    int32_t refresh_fields[NF];
+    sph_halo_stats st{};
+    std::string err;
+};
+
+namespace {
+
+#define H_TRY(call)                                                                                              \
+    do {                                                                                                         \
+        const int st_ = (call);                                                                                  \
+        if (st_ != SPH_OK) {                                                                                     \
+            const char *m_ = sph_last_error(h->c);                                                               \
+            h->err = std::string(#call) + ": " + ((m_ && *m_) ? m_ : sph_strerror(st_));                        \
+            return st_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+#define H_HIP(call)                                                                                              \
+    do {                                                                                                         \
+        const hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return SPH_ERR_HIP; } \
+    } while (0)
+#define H_TR(call)                                                                                               \
+    do {                                                                                                         \
+        const int st_ = (call);                                                                                  \
+        if (st_ != SPH_OK) { h->err = h->tr->err; return st_; }                                                  \
+    } while (0)
+
+// s1 continues after what s0 has queued so far / s0 continues after what s1 has queued so far
+int s0_then_s1(sph_halo *h) { H_HIP(hipEventRecord(h->e01, h->s0)); H_HIP(hipStreamWaitEvent(h->s1, h->e01, 0)); return SPH_OK; }
+int s1_then_s0(sph_halo *h) { H_HIP(hipEventRecord(h->e10, h->s1)); H_HIP(hipStreamWaitEvent(h->s0, h->e10, 0)); return SPH_OK; }
+
+int host_wait(sph_halo *h, hipStream_t s) {
+    H_HIP(hipStreamSynchronize(s));
+    h->st.host_waits++;
+    return SPH_OK;
+}
+
+int common_init(sph_halo *h) {
+    if (h->P < 1 || h->P > MAXP || h->rank < 0 || h->rank >= h->P) { h->err = "1 <= nranks <= 64, 0 <= rank < nranks"; return SPH_ERR_ARG; }
+    sph_params p;
+    H_TRY(sph_get_params(h->c, &p));
+    if (p.flags & (SPH_FLAG_VARIABLE_H | SPH_FLAG_SELF_GRAVITY | SPH_FLAG_ACCRETE_CULL | SPH_FLAG_SINK_CREATION)) {
+        h->err = "sph_halo: fixed-h contexts without self-gravity, accretion or sink creation (the octree paths: summersph_amd/dist.py)";
+        return SPH_ERR_ARG;
+    }
+    h->h = p.h;
+    int dev = 0;
+    if (hipStreamGetDevice(reinterpret_cast<hipStream_t>(sph_stream(h->c)), &dev) != hipSuccess) (void)hipGetDevice(&dev);
+    h->device = dev;
+    DevGuard g(dev);
+    H_HIP(hipStreamCreateWithFlags(&h->s0, hipStreamNonBlocking));
+    if (!h->s1) { H_HIP(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking)); h->own_s1 = true; }
+    H_HIP(hipEventCreateWithFlags(&h->e01, hipEventDisableTiming));
+    H_HIP(hipEventCreateWithFlags(&h->e10, hipEventDisableTiming));
+    H_HIP(hipEventCreateWithFlags(&h->e_pred, hipEventDisableTiming));
+    H_TRY(sph_set_stream(h->c, h->s0));
+    H_TRY(sph_set_rank(h->c, h->rank, h->P));
+    const size_t nd = (size_t)h->P * (SPH_PARTIALS + 6) + (size_t)h->P * h->P + h->P + 64;
+    H_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin), nd * sizeof(double), hipHostMallocDefault));
+    h->pin_part = h->pin;
+    h->pin_boxes = h->pin_part + (size_t)h->P * SPH_PARTIALS;
+    h->pin_cnt = reinterpret_cast<int64_t *>(h->pin_boxes + (size_t)h->P * 6);
+    h->pin_row = h->pin_cnt + (size_t)h->P * h->P;
+    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_first[q] = 0; h->ghost_count[q] = 0; }
+    h->edges.n = 0;
+    return SPH_OK;
+}
+
+// every rank's row of P int64 -> the P x P matrix on the host (row = sender)
+int gather_counts(sph_halo *h, const int64_t *mine, int64_t *matrix) {
+    const int P = h->P;
+    if (P == 1) { matrix[0] = mine[0]; return SPH_OK; }
+    H_HIP(h->cnt.need((size_t)P * 8));
+    H_HIP(h->cntall.need((size_t)P * P * 8));
+    for (int q = 0; q < P; q++) h->pin_row[q] = mine[q];
+    H_HIP(hipMemcpyAsync(h->cnt.p, h->pin_row, (size_t)P * 8, hipMemcpyHostToDevice, h->s1));
+    H_TR(h->tr->allgather(h->cnt.p, h->cntall.p, (size_t)P * 8, h->s1));
+    h->st.collectives++;
+    H_HIP(hipMemcpyAsync(h->pin_cnt, h->cntall.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, h->s1));
+    if (int st = host_wait(h, h->s1)) return st;
+    for (int k = 0; k < P * P; k++) matrix[k] = h->pin_cnt[k];
+    return SPH_OK;
+}
+
+// one grouped round of `width` rows per particle: sendb[q] holds width * send_n[q] doubles, recvb[q] gets width * recv_n[q]
+int p2p(sph_halo *h, const int64_t *send_n, const int64_t *recv_n, int width) {
+    const void *sp[MAXP];
+    void *rp[MAXP];
+    size_t sb[MAXP], rb[MAXP];
+    for (int q = 0; q < h->P; q++) {
+        sb[q] = (size_t)send_n[q] * width * 8;
+        rb[q] = (size_t)recv_n[q] * width * 8;
+        if (rb[q]) H_HIP(h->recvb[q].need(rb[q]));
+        sp[q] = h->sendb[q].p;
+        rp[q] = h->recvb[q].p;
+    }
+    H_TR(h->tr->exchange(sp, sb, rp, rb, h->s1));
+    h->st.exchanges++;
+    return SPH_OK;
+}
+
+int ensure_reserve(sph_halo *h, int64_t n) {
+    if (n + n / 8 + 32768 > h->reserved) {            // room for the ghost swaps; grows rarely (a re-allocation)
+        h->reserved = n + n / 4 + 65536;
+        H_TRY(sph_reserve(h->c, h->reserved));
+    }
+    return SPH_OK;
+}
+
+// particles that left their slab change owner (dist.py _migrate)
+int migrate(sph_halo *h) {
+    const int P = h->P;
+    const int64_t n = h->n_owned;
+    h->st.migrations++;
+    H_HIP(h->own.need((size_t)std::max<int64_t>(n, 1) * NF * 8));
+    H_HIP(h->dest.need((size_t)std::max<int64_t>(n, 1) * 4));
+    H_HIP(h->cnt.need((size_t)std::max(P, 2) * 8));
+    if (n > 0) H_TRY(sph_gather_fields_dev(h->c, NF, STATE, n, nullptr, h->own.as<double>()));
+    H_HIP(hipMemsetAsync(h->cnt.p, 0, (size_t)P * 8, h->s0));
+    if (n > 0) {
+        dest_kernel<<<blocks_for(n), 256, 0, h->s0>>>(h->own.as<double>(), n, h->edges, h->dest.as<int32_t>(), h->cnt.as<unsigned long long>());
+        H_HIP(hipGetLastError());
+    }
+    int64_t mine[MAXP];
+    H_HIP(hipMemcpyAsync(h->pin_row, h->cnt.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->s0));
+    if (int st = host_wait(h, h->s0)) return st;
+    for (int q = 0; q < P; q++) mine[q] = h->pin_row[q];
+    std::vector<int64_t> cm((size_t)P * P);
+    if (int st = gather_counts(h, mine, cm.data())) return st;
+    int64_t moved = 0;
+    for (int a = 0; a < P; a++) for (int b = 0; b < P; b++) if (a != b) moved += cm[(size_t)a * P + b];
+    if (moved == 0) return SPH_OK;                     // nobody moved anywhere: the contexts stay as they are
+
+    int64_t out[MAXP], inc[MAXP];
+    for (int q = 0; q < P; q++) { out[q] = q == h->rank ? 0 : cm[(size_t)h->rank * P + q]; inc[q] = q == h->rank ? 0 : cm[(size_t)q * P + h->rank]; }
+    const int64_t n_keep = cm[(size_t)h->rank * P + h->rank];
+    H_HIP(h->flags.need((size_t)std::max<int64_t>(n, 1)));
+    H_HIP(h->sel_count.need(8));
+    size_t tmp_bytes = 0;
+    if (n > 0) {
+        H_HIP(rocprim::select(nullptr, tmp_bytes, rocprim::counting_iterator<int64_t>(0), h->flags.as<uint8_t>(), h->keep_ids.as<int64_t>(),
+                              h->sel_count.as<size_t>(), (size_t)n, h->s0));
+        H_HIP(h->sel_tmp.need(tmp_bytes));
+    }
+    auto select_dest = [&](int q, DevBuf &ids, int64_t expect) -> int {
+        H_HIP(ids.need((size_t)std::max<int64_t>(expect, 1) * 8));
+        if (expect == 0) return SPH_OK;
+        flag_kernel<<<blocks_for(n), 256, 0, h->s0>>>(h->dest.as<int32_t>(), n, q, h->flags.as<uint8_t>());
+        H_HIP(hipGetLastError());
+        size_t tb = tmp_bytes;
+        H_HIP(rocprim::select(h->sel_tmp.p, tb, rocprim::counting_iterator<int64_t>(0), h->flags.as<uint8_t>(), ids.as<int64_t>(),
+                              h->sel_count.as<size_t>(), (size_t)n, h->s0));
+        return SPH_OK;
+    };
+    // payload per destination: the 9 state rows + the global number as a 10th row
+    for (int q = 0; q < P; q++) {
+        if (out[q] == 0) continue;
+        if (int st = select_dest(q, h->ids[q], out[q])) return st;
+        H_HIP(h->sendb[q].need((size_t)out[q] * (NF + 1) * 8));
+        gather_rows<<<blocks_for(out[q]), 256, 0, h->s0>>>(h->own.as<double>(), n, h->ids[q].as<int64_t>(), out[q], NF, h->sendb[q].as<double>(), out[q], 0);
+        gid_to_double<<<blocks_for(out[q]), 256, 0, h->s0>>>(h->gid.as<int64_t>(), h->ids[q].as<int64_t>(), out[q], h->sendb[q].as<double>() + (size_t)NF * out[q]);
+        H_HIP(hipGetLastError());
+    }
+    if (int st = select_dest(h->rank, h->keep_ids, n_keep)) return st;
+    if (int st = s0_then_s1(h)) return st;
+    if (int st = p2p(h, out, inc, NF + 1)) return st;
+    if (int st = s1_then_s0(h)) return st;
+    int64_t n_new = n_keep;
+    for (int q = 0; q < P; q++) n_new += inc[q];
+    H_HIP(h->newbuf.need((size_t)std::max<int64_t>(n_new, 1) * NF * 8));
+    H_HIP(h->gid_new.need((size_t)std::max<int64_t>(n_new, 1) * 8));
+    if (n_keep > 0) {
+        gather_rows<<<blocks_for(n_keep), 256, 0, h->s0>>>(h->own.as<double>(), n, h->keep_ids.as<int64_t>(), n_keep, NF, h->newbuf.as<double>(), n_new, 0);
+        gather_gid<<<blocks_for(n_keep), 256, 0, h->s0>>>(h->gid.as<int64_t>(), h->keep_ids.as<int64_t>(), n_keep, h->gid_new.as<int64_t>());
+        H_HIP(hipGetLastError());
+    }
+    int64_t off = n_keep;
+    for (int q = 0; q < P; q++) {
+        if (inc[q] == 0) continue;
+        gather_rows<<<blocks_for(inc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>(), inc[q], nullptr, inc[q], NF, h->newbuf.as<double>(), n_new, off);
+        double_to_gid<<<blocks_for(inc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>() + (size_t)NF * inc[q], inc[q], h->gid_new.as<int64_t>() + off);
+        H_HIP(hipGetLastError());
+        off += inc[q];
+    }
+    if (int st = ensure_reserve(h, n_new)) return st;
+    const double *r = h->newbuf.as<double>();
+    H_TRY(sph_upload_dev(h->c, n_new, r, r + n_new, r + 2 * n_new, r + 3 * n_new, r + 4 * n_new, r + 5 * n_new, r + 6 * n_new, r + 7 * n_new, r + 8 * n_new));
+    std::swap(h->gid, h->gid_new);
+    h->n_owned = n_new;
+    h->st.migrated += moved;
+    for (int q = 0; q < P; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; }
+    return SPH_OK;
+}
+
+// who needs which of my particles, ship them, swap them in (dist.py _exchange_ghosts)
+int exchange_ghosts(sph_halo *h) {
+    const int P = h->P;
+    bool use_pred = h->pred_for_drift && h->pred_valid;
+    h->pred_for_drift = false;
+    std::vector<double> boxes((size_t)P * 6);
+    if (use_pred) {
+        H_HIP(hipEventSynchronize(h->e_pred));
+        h->st.host_waits++;
+        for (int q = 0; q < P; q++)
+            for (int a = 0; a < 6; a++) {
+                const double v = h->pin_part[(size_t)q * SPH_PARTIALS + PRED_SLOT + a];
+                if (std::isnan(v)) use_pred = false;             // some rank had no prediction
+                boxes[(size_t)q * 6 + a] = v;
+            }
+    }
+    if (!use_pred) {
+        H_HIP(h->box.need(6 * 8));
+        H_HIP(h->boxes.need((size_t)P * 6 * 8));
+        H_TRY(sph_owned_bbox(h->c, nullptr, h->box.as<double>()));
+        if (int st = s0_then_s1(h)) return st;
+        H_TR(h->tr->allgather(h->box.p, h->boxes.p, 6 * 8, h->s1));
+        h->st.collectives++;
+        H_HIP(hipMemcpyAsync(h->pin_boxes, h->boxes.p, (size_t)P * 6 * 8, hipMemcpyDeviceToHost, h->s1));
+        if (int st = host_wait(h, h->s1)) return st;
+        for (int k = 0; k < P * 6; k++) boxes[k] = h->pin_boxes[k];
+    }
+    const double r = 2.0 * h->h * (1.0 + 1e-9);
+    auto finite6 = [&](int q) { for (int a = 0; a < 6; a++) if (!std::isfinite(boxes[(size_t)q * 6 + a])) return false; return true; };
+    const bool mine_ok = finite6(h->rank);
+    const double *me = &boxes[(size_t)h->rank * 6];
+    int peers[MAXP], npeers = 0;
+    double sel[MAXP * 6];
+    for (int q = 0; q < P; q++) {
+        h->send_count[q] = 0;
+        if (q == h->rank || !mine_ok || !finite6(q)) continue;
+        const double *b = &boxes[(size_t)q * 6];
+        bool touch = true;
+        for (int a = 0; a < 3; a++) if (me[3 + a] < b[a] - r || me[a] > b[3 + a] + r) touch = false;
+        if (!touch) continue;
+        for (int a = 0; a < 3; a++) { sel[npeers * 6 + a] = b[a] - r; sel[npeers * 6 + 3 + a] = b[3 + a] + r; }
+        peers[npeers++] = q;
+    }
+    int64_t counts[MAXP], selc[MAXP];
+    for (int q = 0; q < P; q++) counts[q] = 0;
+    if (npeers > 0) {
+        H_TRY(sph_select_boxes(h->c, npeers, sel, selc));
+        h->st.host_waits++;
+        for (int b = 0; b < npeers; b++) counts[peers[b]] = selc[b];
+    }
+    std::vector<int64_t> cm((size_t)P * P);
+    if (int st = gather_counts(h, counts, cm.data())) return st;
+    int64_t rc[MAXP], total = 0;
+    for (int q = 0; q < P; q++) { rc[q] = q == h->rank ? 0 : cm[(size_t)q * P + h->rank]; total += rc[q]; }
+    // every ghost about to arrive lies inside its owner's box: particles farther than 2h from all of them cannot have a
+    // ghost neighbour (their forces do not wait for the ghost fields)
+    double bnd[MAXP * 6];
+    int nb = 0;
+    for (int q = 0; q < P; q++) if (rc[q] > 0) { for (int a = 0; a < 6; a++) bnd[nb * 6 + a] = boxes[(size_t)q * 6 + a]; nb++; }
+    H_TRY(sph_set_boundary_boxes(h->c, nb, bnd));
+    for (int b = 0; b < npeers; b++) {
+        const int q = peers[b];
+        const int64_t cnt = counts[q];
+        h->send_count[q] = cnt;
+        if (cnt == 0) continue;
+        H_HIP(h->ids[q].need((size_t)cnt * 8));
+        H_HIP(h->sendb[q].need((size_t)cnt * (NF + 1) * 8));
+        H_TRY(sph_selected_ids_dev(h->c, b, cnt, h->ids[q].as<int64_t>()));
+        H_TRY(sph_gather_fields_dev(h->c, NF, STATE, cnt, h->ids[q].as<int64_t>(), h->sendb[q].as<double>()));
+    }
+    if (h->n_owned + total > h->reserved) {
+        h->err = "sph_halo: more ghosts than the reserved slots hold (n_owned + ghosts > n_owned * 5/4 + 65536)";
+        // the peers are already inside the exchange: take part in it before giving up, or they would wait forever
+    }
+    if (int st = s0_then_s1(h)) return st;
+    if (int st = p2p(h, h->send_count, rc, NF)) return st;
+    if (int st = s1_then_s0(h)) return st;
+    if (h->n_owned + total > h->reserved) return SPH_ERR_NOMEM;
+    H_HIP(h->ghosts.need((size_t)std::max<int64_t>(total, 1) * NF * 8));
+    int64_t first = h->n_owned, off = 0;
+    for (int q = 0; q < P; q++) {
+        h->ghost_first[q] = first;
+        h->ghost_count[q] = rc[q];
+        if (rc[q] > 0) {
+            gather_rows<<<blocks_for(rc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>(), rc[q], nullptr, rc[q], NF, h->ghosts.as<double>(), total, off);
+            H_HIP(hipGetLastError());
+        }
+        first += rc[q];
+        off += rc[q];
+    }
+    h->st.ghosts = total;
+    H_TRY(sph_replace_ghosts_dev(h->c, total, h->ghosts.as<double>()));
+    return SPH_OK;
+}
+
+// ship the listed fields of the particles my peers hold as ghosts: packed on s0, sent on s1 while s0 goes on
+int refresh_start(sph_halo *h, int nf, const int32_t *fields) {
+    for (int q = 0; q < h->P; q++) {
+        if (h->send_count[q] == 0) continue;
+        H_HIP(h->sendb[q].need((size_t)h->send_count[q] * nf * 8));
+        H_TRY(sph_gather_fields_dev(h->c, nf, fields, h->send_count[q], h->ids[q].as<int64_t>(), h->sendb[q].as<double>()));
+    }
+    if (int st = s0_then_s1(h)) return st;
+    if (int st = p2p(h, h->send_count, h->ghost_count, nf)) return st;
+    H_HIP(hipEventRecord(h->e10, h->s1));
+    h->refresh_pending = true;
+    h->refresh_nf = nf;
+    for (int f = 0; f < nf; f++) h->refresh_fields[f] = fields[f];
+    return SPH_OK;
+}
+
+// ... and scatter what the peers sent into my ghost slots once it has arrived
+int refresh_finish(sph_halo *h) {
+    if (!h->refresh_pending) return SPH_OK;
+    h->refresh_pending = false;
+    H_HIP(hipStreamWaitEvent(h->s0, h->e10, 0));
+    for (int q = 0; q < h->P; q++)
+        if (h->ghost_count[q] > 0)
+            H_TRY(sph_scatter_fields_dev(h->c, h->refresh_nf, h->refresh_fields, h->ghost_first[q], h->ghost_count[q], h->recvb[q].as<double>()));
+    return SPH_OK;
+}
+
+// sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied; the same message
+// carries every rank's predicted box after the coming kick + drift (dist.py _reduce)
+int reduce(sph_halo *h) {
+    H_HIP(h->part.need(SPH_PARTIALS * 8));
+    H_TRY(sph_pack_partials_dev(h->c, h->part.as<double>()));
+    if (h->P == 1) {
+        H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, h->dt_pending ? 1 : 0));
+        h->pred_valid = false;
+    } else {
+        H_HIP(h->allpart.need((size_t)h->P * SPH_PARTIALS * 8));
+        if (int st = s0_then_s1(h)) return st;
+        H_TR(h->tr->allgather(h->part.p, h->allpart.p, SPH_PARTIALS * 8, h->s1));
+        h->st.collectives++;
+        // to the host without stalling either stream: read after the drift
+        H_HIP(hipMemcpyAsync(h->pin_part, h->allpart.p, (size_t)h->P * SPH_PARTIALS * 8, hipMemcpyDeviceToHost, h->s1));
+        H_HIP(hipEventRecord(h->e_pred, h->s1));
+        H_HIP(hipStreamWaitEvent(h->s0, h->e_pred, 0));
+        H_TRY(sph_apply_partials_dev(h->c, h->allpart.as<double>(), h->P, SPH_PARTIALS, h->dt_pending ? 1 : 0));
+        h->pred_valid = true;
+    }
+    h->dt_pending = false;
+    return SPH_OK;
+}
+
+// one force evaluation: create_tree .. find_forces of the reference, [F]:894-898 (dist.py evaluate)
+int evaluate(sph_halo *h) {
+    static const int32_t RHO[1] = {SPH_F_RHO};
+    static const int32_t VEL[5] = {SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_ALPHA};
+    const bool multi = h->P > 1;
+    if (h->pos_dirty) {
+        if (multi && h->migrate_every > 0 && h->edges.n == h->P - 1 && h->since_migrate >= h->migrate_every) {
+            if (int st = migrate(h)) return st;
+            h->since_migrate = 0;
+            h->pred_for_drift = false;          // ownership changed: the predicted boxes are void
+        }
+        if (multi) if (int st = exchange_ghosts(h)) return st;
+        H_TRY(sph_density(h->c));
+        if (multi) if (int st = refresh_start(h, 1, RHO)) return st;
+    } else {
+        // the density sum needs positions and masses only: it runs while the ghosts' v, u, alpha travel
+        if (multi && h->vel_dirty) if (int st = refresh_start(h, 5, VEL)) return st;
+        H_TRY(sph_density(h->c));
+    }
+    h->pos_dirty = h->vel_dirty = false;
+    if (multi) {
+        // ... and so do the forces of the wavefronts that cannot see a ghost
+        H_TRY(sph_forces_part(h->c, 1));
+        if (int st = refresh_finish(h)) return st;
+        H_TRY(sph_refresh_eos_ghosts(h->c));
+        H_TRY(sph_forces_part(h->c, 2));
+    } else {
+        H_TRY(sph_forces(h->c));
+    }
+    return reduce(h);
+}
+
+int step(sph_halo *h) {
+    if (int st = evaluate(h)) return st;
+    H_TRY(sph_kick_devdt(h->c));
+    H_TRY(sph_drift_devdt(h->c));
+    h->pos_dirty = true;
+    h->pred_for_drift = true;                   // the reduction above predicted where this drift takes everybody
+    h->since_migrate++;
+    if (int st = evaluate(h)) return st;
+    H_TRY(sph_kick_devdt(h->c));
+    H_TRY(sph_dt_candidate_dev(h->c));           // get_next_timestep's local part, [F]:845-851; reduced with the next evaluation
+    h->vel_dirty = true;
+    h->dt_pending = true;
+    return SPH_OK;
+}
+
+// reduce a pending dt candidate now (end of a run): t += dt and [F]:855-858 on every rank
+int finish_dt(sph_halo *h) {
+    if (!h->dt_pending) return SPH_OK;
+    H_HIP(h->part.need(SPH_PARTIALS * 8));
+    H_HIP(h->row.need(SPH_PARTIALS * 8));
+    H_TRY(sph_pack_partials_dev(h->c, h->part.as<double>()));
+    if (h->P == 1) {
+        H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, 1));
+    } else {
+        H_HIP(h->allpart.need((size_t)h->P * SPH_PARTIALS * 8));
+        if (int st = s0_then_s1(h)) return st;
+        H_TR(h->tr->allgather(h->part.p, h->allpart.p, SPH_PARTIALS * 8, h->s1));
+        h->st.collectives++;
+        if (int st = s1_then_s0(h)) return st;
+        // the sink accelerations in the blocks are the totals every rank already holds: keep them, apply only the dt part
+        min_dt_row<<<1, 256, 0, h->s0>>>(h->allpart.as<double>(), h->P, h->rank, h->row.as<double>());
+        H_HIP(hipGetLastError());
+        H_TRY(sph_apply_partials_dev(h->c, h->row.as<double>(), 1, SPH_PARTIALS, 1));
+    }
+    h->dt_pending = false;
+    h->pred_valid = false;
+    return SPH_OK;
+}
+
+void destroy_impl(sph_halo *h) {
+    DevGuard g(h->device);
+    if (h->s0) (void)hipStreamSynchronize(h->s0);
+    if (h->s1) (void)hipStreamSynchronize(h->s1);
+    if (h->c && h->s0) (void)sph_set_stream(h->c, nullptr);     // the context outlives this object: off our stream before it goes
+    delete h->tr;
+    for (DevBuf *b : {&h->gid, &h->gid_new, &h->own, &h->newbuf, &h->part, &h->allpart, &h->row, &h->box, &h->boxes, &h->cnt, &h->cntall,
+                      &h->ghosts, &h->dest, &h->flags, &h->keep_ids, &h->sel_tmp, &h->sel_count}) b->release();
+    for (int q = 0; q < MAXP; q++) { h->sendb[q].release(); h->recvb[q].release(); h->ids[q].release(); }
+    if (h->pin) (void)hipHostFree(h->pin);
+    for (hipEvent_t e : {h->e01, h->e10, h->e_pred}) if (e) (void)hipEventDestroy(e);
+    if (h->s0) (void)hipStreamDestroy(h->s0);
+    if (h->s1 && h->own_s1) (void)hipStreamDestroy(h->s1);
+    delete h;
+}
+
+thread_local std::string g_create_err;
+
+}  // namespace
+
+extern "C" {
+
+int sph_halo_unique_id(void *id128) {
+    if (!id128) return SPH_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == SPH_HALO_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SPH_ERR_HIP;
+    std::memcpy(id128, &id, sizeof id);
+    return SPH_OK;
+}
+
+static int create_common(sph_halo *h, sph_halo **out) {
+    const int st = common_init(h);
+    if (st != SPH_OK) { g_create_err = h->err; destroy_impl(h); return st; }
+    *out = h;
+    return SPH_OK;
+}
+
+int sph_halo_create(sph_ctx *ctx, const void *id128, int32_t rank, int32_t nranks, sph_halo **out) {
+    if (!ctx || !id128 || !out || nranks < 1 || nranks > MAXP || rank < 0 || rank >= nranks) return SPH_ERR_ARG;
+    int dev = 0;
+    if (hipStreamGetDevice(reinterpret_cast<hipStream_t>(sph_stream(ctx)), &dev) != hipSuccess) (void)hipGetDevice(&dev);
+    DevGuard g(dev);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    auto *tr = new RcclTransport();
+    tr->P = nranks;
+    tr->own = true;
+    const ncclResult_t r = ncclCommInitRank(&tr->comm, nranks, id, rank);
+    if (r != ncclSuccess) { g_create_err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); tr->comm = nullptr; delete tr; return SPH_ERR_HIP; }
+    auto *h = new sph_halo();
+    h->c = ctx; h->rank = rank; h->P = nranks; h->tr = tr;
+    return create_common(h, out);
+}
+
+int sph_halo_attach(sph_ctx *ctx, void *nccl_comm, void *comm_stream, int32_t rank, int32_t nranks, sph_halo **out) {
+    if (!ctx || !nccl_comm || !out || nranks < 1 || nranks > MAXP || rank < 0 || rank >= nranks) return SPH_ERR_ARG;
+    auto *tr = new RcclTransport();
+    tr->P = nranks;
+    tr->comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    tr->own = false;
+    auto *h = new sph_halo();
+    h->c = ctx; h->rank = rank; h->P = nranks; h->tr = tr;
+    if (comm_stream) { h->s1 = reinterpret_cast<hipStream_t>(comm_stream); h->own_s1 = false; }
+    return create_common(h, out);
+}
+
+void *sph_halo_hub_create(int32_t nranks) {
+    if (nranks < 1 || nranks > MAXP) return nullptr;
+    return new Hub(nranks);
+}
+
+void sph_halo_hub_destroy(void *hub) {
+    auto *hb = static_cast<Hub *>(hub);
+    if (!hb) return;
+    for (int q = 0; q < MAXP; q++) { if (hb->ready[q]) (void)hipEventDestroy(hb->ready[q]); if (hb->done[q]) (void)hipEventDestroy(hb->done[q]); }
+    delete hb;
+}
+
+int sph_halo_create_inproc(sph_ctx *ctx, void *hub, int32_t rank, int32_t nranks, sph_halo **out) {
+    auto *hb = static_cast<Hub *>(hub);
+    if (!ctx || !hb || !out || nranks != hb->P || rank < 0 || rank >= nranks) return SPH_ERR_ARG;
+    int dev = 0;
+    if (hipStreamGetDevice(reinterpret_cast<hipStream_t>(sph_stream(ctx)), &dev) != hipSuccess) (void)hipGetDevice(&dev);
+    DevGuard g(dev);
+    if (hipEventCreateWithFlags(&hb->ready[rank], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&hb->done[rank], hipEventDisableTiming) != hipSuccess) return SPH_ERR_HIP;
+    auto *tr = new InprocTransport();
+    tr->hub = hb;
+    tr->rank = rank;
+    auto *h = new sph_halo();
+    h->c = ctx; h->rank = rank; h->P = nranks; h->tr = tr;
+    return create_common(h, out);
+}
+
+int sph_halo_destroy(sph_halo *h) {
+    if (!h) return SPH_ERR_ARG;
+    destroy_impl(h);
+    return SPH_OK;
+}
+
+const char *sph_halo_last_error(const sph_halo *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int sph_halo_set_slabs(sph_halo *h, const double *edges, int32_t migrate_every) {
+    if (!h || migrate_every < 0 || (h->P > 1 && !edges)) return SPH_ERR_ARG;
+    for (int k = 0; k + 1 < h->P; k++) {
+        if (k > 0 && !(edges[k] >= edges[k - 1])) { h->err = "sph_halo_set_slabs: edges must ascend"; return SPH_ERR_ARG; }
+        h->edges.e[k] = edges[k];
+    }
+    h->edges.n = h->P - 1;
+    h->migrate_every = migrate_every;
+    return SPH_OK;
+}
+
+int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, const double *z, const double *vx, const double *vy,
+                    const double *vz, const double *u, const double *m, const double *alpha, const int64_t *gid) {
+    if (!h || n < 0) return SPH_ERR_ARG;
+    DevGuard g(h->device);
+    if (int st = ensure_reserve(h, n)) return st;
+    H_TRY(sph_upload(h->c, n, x, y, z, vx, vy, vz, u, m, alpha));
+    H_HIP(h->gid.need((size_t)std::max<int64_t>(n, 1) * 8));
+    if (n > 0) {
+        if (gid) H_HIP(hipMemcpyAsync(h->gid.p, gid, (size_t)n * 8, hipMemcpyHostToDevice, h->s0));
+        else { iota64<<<blocks_for(n), 256, 0, h->s0>>>(h->gid.as<int64_t>(), n); H_HIP(hipGetLastError()); }
+        H_HIP(hipStreamSynchronize(h->s0));
+    }
+    h->n_owned = n;
+    h->uploaded = true;
+    h->pos_dirty = true; h->vel_dirty = false; h->dt_pending = false; h->pred_for_drift = false; h->pred_valid = false;
+    h->since_migrate = 0;
+    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; }
+    return SPH_OK;
+}
+
+int sph_halo_run(sph_halo *h, int32_t nsteps, double *dt, double *t) {
+    if (!h || !dt || !t || nsteps < 0) return SPH_ERR_ARG;
+    if (!h->uploaded) { h->err = "sph_halo_run: call sph_halo_upload first"; return SPH_ERR_STATE; }
+    DevGuard g(h->device);
+    H_TRY(sph_set_dt(h->c, *dt, *t));
+    for (int s = 0; s < nsteps; s++) if (int st = step(h)) return st;
+    if (int st = finish_dt(h)) return st;
+    H_TRY(sph_get_dt(h->c, dt, t));
+    return SPH_OK;
+}
+
+int64_t sph_halo_count(const sph_halo *h) { return h ? h->n_owned : -1; }
+
+int sph_halo_download(sph_halo *h, int64_t capacity, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *u,
+                      double *m, double *alpha, int64_t *gid) {
+    if (!h || capacity < h->n_owned) return SPH_ERR_ARG;
+    DevGuard g(h->device);
+    const int64_t n = h->n_owned;
+    if (n == 0) return SPH_OK;
+    H_HIP(h->own.need((size_t)n * NF * 8));
+    H_TRY(sph_gather_fields_dev(h->c, NF, STATE, n, nullptr, h->own.as<double>()));
+    double *dst[NF] = {x, y, z, vx, vy, vz, u, m, alpha};
+    for (int f = 0; f < NF; f++)
+        if (dst[f]) H_HIP(hipMemcpyAsync(dst[f], h->own.as<double>() + (size_t)f * n, (size_t)n * 8, hipMemcpyDeviceToHost, h->s0));
+    if (gid) H_HIP(hipMemcpyAsync(gid, h->gid.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->s0));
+    H_HIP(hipStreamSynchronize(h->s0));
+    return SPH_OK;
+}
+
+int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z, double *vx,
+                         double *vy, double *vz, double *u, double *m, double *alpha, int64_t *gid) {
+    if (!h || root < 0 || root >= h->P || !n_total) return SPH_ERR_ARG;
+    DevGuard g(h->device);
+    const int P = h->P;
+    const int64_t n = h->n_owned;
+    int64_t mine[MAXP];
+    for (int q = 0; q < P; q++) mine[q] = q == root ? n : 0;       // row r of the matrix: what rank r sends to each rank
+    std::vector<int64_t> cm((size_t)P * P);
+    if (int st = gather_counts(h, mine, cm.data())) return st;
+    int64_t total = 0;
+    for (int q = 0; q < P; q++) total += cm[(size_t)q * P + root];
+    *n_total = total;
+    const bool is_root = h->rank == root;
+    const bool fits = !is_root || capacity >= total;
+    // payload: the 9 state rows + the global number
+    H_HIP(h->own.need((size_t)std::max<int64_t>(n, 1) * (NF + 1) * 8));
+    if (n > 0) {
+        H_TRY(sph_gather_fields_dev(h->c, NF, STATE, n, nullptr, h->own.as<double>()));
+        gid_to_double<<<blocks_for(n), 256, 0, h->s0>>>(h->gid.as<int64_t>(), nullptr, n, h->own.as<double>() + (size_t)NF * n);
+        H_HIP(hipGetLastError());
+    }
+    int64_t send_n[MAXP], recv_n[MAXP];
+    for (int q = 0; q < P; q++) { send_n[q] = 0; recv_n[q] = 0; }
+    if (!is_root) {
+        send_n[root] = n;
+        // p2p sends out of sendb: let it alias the payload
+        std::swap(h->sendb[root], h->own);
+    } else {
+        for (int q = 0; q < P; q++) if (q != root) recv_n[q] = cm[(size_t)q * P + root];
+    }
+    int st = s0_then_s1(h);
+    if (st == SPH_OK) st = p2p(h, send_n, recv_n, NF + 1);
+    if (st == SPH_OK) st = host_wait(h, h->s1);
+    if (!is_root) std::swap(h->sendb[root], h->own);
+    if (st != SPH_OK) return st;
+    if (!is_root) return SPH_OK;
+    if (!fits) { h->err = "sph_halo_gather_root: capacity below the total particle count"; return SPH_ERR_ARG; }
+    // to the host block by block, then into global-number order
+    std::vector<double> blk;
+    std::vector<int64_t> order((size_t)total);
+    std::vector<double> all((size_t)total * (NF + 1));
+    int64_t off = 0;
+    for (int q = 0; q < P; q++) {
+        const int64_t nq = cm[(size_t)q * P + root];
+        if (nq == 0) continue;
+        const double *src = q == root ? h->own.as<double>() : h->recvb[q].as<double>();
+        blk.resize((size_t)nq * (NF + 1));
+        H_HIP(hipMemcpy(blk.data(), src, blk.size() * 8, hipMemcpyDeviceToHost));
+        for (int r = 0; r <= NF; r++) std::memcpy(&all[(size_t)r * total + off], &blk[(size_t)r * nq], (size_t)nq * 8);
+        off += nq;
+    }
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    const double *gd = &all[(size_t)NF * total];
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gd[a] < gd[b]; });
+    double *dst[NF] = {x, y, z, vx, vy, vz, u, m, alpha};
+    for (int f = 0; f < NF; f++)
+        if (dst[f]) for (int64_t k = 0; k < total; k++) dst[f][k] = all[(size_t)f * total + order[(size_t)k]];
+    if (gid) for (int64_t k = 0; k < total; k++) gid[k] = (int64_t)gd[order[(size_t)k]];
+    return SPH_OK;
+}
+
+int sph_halo_get_stats(const sph_halo *h, sph_halo_stats *out) {
+    if (!h || !out) return SPH_ERR_ARG;
+    *out = h->st;
+    return SPH_OK;
+}
+
+int sph_halo_selftest(sph_halo *h, int64_t count) {
+    if (!h || count < 1) return SPH_ERR_ARG;
+    DevGuard g(h->device);
+    const int P = h->P;
+    auto value = [](int from, int to) { return 1.0e6 * from + 1.0e3 * to; };
+    int64_t cn[MAXP];
+    for (int q = 0; q < P; q++) {
+        cn[q] = count;
+        H_HIP(h->sendb[q].need((size_t)count * 8));
+        pattern_kernel<<<blocks_for(count), 256, 0, h->s0>>>(h->sendb[q].as<double>(), count, value(h->rank, q));
+        H_HIP(hipGetLastError());
+    }
+    if (int st = s0_then_s1(h)) return st;
+    if (int st = p2p(h, cn, cn, 1)) return st;
+    if (int st = host_wait(h, h->s1)) return st;
+    std::vector<double> got((size_t)count);
+    for (int q = 0; q < P; q++) {
+        H_HIP(hipMemcpy(got.data(), h->recvb[q].p, (size_t)count * 8, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < count; k++)
+            if (got[(size_t)k] != value(q, h->rank) + (double)k) { h->err = "sph_halo_selftest: point-to-point payload differs"; return SPH_ERR_STATE; }
+    }
+    H_HIP(h->own.need((size_t)count * P * 8));
+    if (int st = s0_then_s1(h)) return st;
+    H_TR(h->tr->allgather(h->sendb[0].p, h->own.p, (size_t)count * 8, h->s1));
+    h->st.collectives++;
+    if (int st = host_wait(h, h->s1)) return st;
+    for (int q = 0; q < P; q++) {
+        H_HIP(hipMemcpy(got.data(), h->own.as<double>() + (size_t)q * count, (size_t)count * 8, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < count; k++)
+            if (got[(size_t)k] != value(q, 0) + (double)k) { h->err = "sph_halo_selftest: all-gather payload differs"; return SPH_ERR_STATE; }
+    }
+    return SPH_OK;
+}
+
+}  // extern "C"

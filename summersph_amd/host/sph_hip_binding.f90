@@ -8,7 +8,7 @@ module sph_hip_binding
   implicit none
   private
   public :: sph_params, sph_stats
-  public :: sph_params_default, sph_ctx_create, sph_ctx_destroy, sph_strerror, sph_last_error, sph_abi_version
+  public :: sph_params_default, sph_ctx_create, sph_ctx_destroy, sph_strerror, sph_last_error, sph_abi_version, sph_get_params
   public :: sph_upload, sph_set_sinks, sph_get_sinks, sph_count
   public :: sph_density, sph_forces, sph_kick, sph_drift, sph_next_dt, sph_step, sph_run
   public :: sph_download_field, sph_download_state, sph_get_stats, sph_get_bbox, sph_synchronize
@@ -58,6 +58,12 @@ module sph_hip_binding
   interface
     integer(c_int) function sph_abi_version() bind(C, name='sph_abi_version')
       import :: c_int
+    end function
+
+    integer(c_int) function sph_get_params(ctx, p) bind(C, name='sph_get_params')
+      import :: c_int, c_ptr, sph_params
+      type(c_ptr), value :: ctx
+      type(sph_params), intent(out) :: p
     end function
 
     integer(c_int) function sph_params_default(p) bind(C, name='sph_params_default')

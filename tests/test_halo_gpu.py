@@ -1,0 +1,165 @@
+"""The native multi-GPU step loop (libsummersph_halo.so, csrc/halo.hip) on the one GPU of the test box.
+
+* in-process transport: 2 and 3 ranks as threads of this process, each with its own context and its own pair of streams;
+  the merged result must match the real reference's trajectory like the single-context run and dist.py's ranks do;
+* RCCL transport with ONE rank: communicator set-up, ncclAllGather and grouped ncclSend/ncclRecv (to itself) really run;
+  more ranks need more GPUs than this pool has (RCCL refuses two ranks on one device).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from summersph_amd import capi, halo, ic
+from summersph_amd.dist import slab_bounds
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+FIELDS = "x y z vx vy vz u alpha".split()
+
+
+def _run_ranks(world, gas, sinks, nsteps, migrate_every=2, collect_root=False):
+    hub = halo.Hub(world)
+    bounds = slab_bounds(gas["x"], world)
+    owner = np.searchsorted(bounds, gas["x"], side="right")
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = capi.Context(device=0)
+            h = halo.Halo.inproc(ctx, hub, rank, world)
+            sel = owner == rank
+            mine = {k: v[sel] for k, v in gas.items()}
+            mine["gid"] = np.nonzero(sel)[0]
+            ctx.set_sinks(sinks)
+            h.set_slabs(bounds, migrate_every)
+            h.upload(mine)
+            dts, t = [1e-2], 0.0
+            for _ in range(nsteps):
+                dt, t = h.run(1, dts[-1], t)
+                dts.append(dt)
+            res = {"dts": dts, "t": t, "state": h.download(), "stats": h.stats(), "sinks": ctx.get_sinks()}
+            if collect_root:
+                res["root"] = h.gather_root(0, gas["x"].size)
+            out[rank] = res
+            h.close(); ctx.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the test below
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    hub.close()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_inproc_ranks_match_reference_fixture(world):
+    g = load_golden("disc3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks(world, gas, sinks, 5, collect_root=True)
+    gid = np.concatenate([p["state"]["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(gid.size))
+    order = np.argsort(gid)
+    for p in parts:
+        assert list(p["dts"]) == list(g["sph_dt_seq"])
+        assert p["stats"].ghosts > 0 and p["stats"].exchanges > 0
+        assert np.array_equal(p["sinks"]["x"], parts[0]["sinks"]["x"])
+    assert sum(p["stats"].migrations for p in parts) > 0
+    for f in FIELDS:
+        merged = np.concatenate([p["state"][f] for p in parts])[order]
+        assert rel_err(merged, g["sph_s5_" + f]) <= 1e-11, f
+    # the collective save: everything on rank 0, in global-number order
+    root = parts[0]["root"]
+    assert parts[1]["root"] is None
+    assert np.array_equal(root["gid"], np.arange(gid.size))
+    for f in FIELDS:
+        assert np.array_equal(root[f], np.concatenate([p["state"][f] for p in parts])[order]), f
+
+
+def test_inproc_single_rank_is_sph_run():
+    """one rank: no ghosts, no messages -- the loop must give what sph_run gives, bit for bit"""
+    g = load_golden("disc3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    one = _run_ranks(1, gas, sinks, 5)[0]
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = 1e-2, 0.0
+    for _ in range(5):
+        dt, t = ctx.run(1, dt, t)
+    ref = {f: ctx.field(f) for f in FIELDS}
+    assert one["dts"][-1] == dt and one["t"] == t
+    order = np.argsort(one["state"]["gid"])
+    for f in FIELDS:
+        assert np.array_equal(one["state"][f][order], ref[f]), f
+    ctx.close()
+
+
+def test_rccl_transport_single_rank():
+    g = load_golden("disc3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    ctx = capi.Context(device=0)
+    h = halo.Halo.rccl(ctx, halo.unique_id(), 0, 1)
+    h.selftest(100000)
+    assert h.stats().exchanges == 1 and h.stats().collectives == 1
+    ctx.set_sinks(sinks)
+    h.set_slabs(np.zeros(0), 2)
+    gas = dict(gas); gas["gid"] = np.arange(gas["x"].size)
+    h.upload(gas)
+    dts, t = [1e-2], 0.0
+    for _ in range(5):
+        dt, t = h.run(1, dts[-1], t)
+        dts.append(dt)
+    assert dts == list(g["sph_dt_seq"])
+    st = h.download()
+    for f in FIELDS:
+        assert rel_err(st[f], g["sph_s5_" + f]) <= 1e-12, f
+    whole = h.gather_root(0, gas["x"].size)
+    assert np.array_equal(whole["x"], st["x"])
+    h.close(); ctx.close()
+
+
+def test_ring_two_ranks_viscosity():
+    """the viscous, asymmetric workload (BASELINE configs[1] shape): 2 ranks against one context, 4 steps"""
+    rows = ic.thin_ring(20000, seed=17)
+    gas, sinks = ic.split_rows(rows)
+    parts = _run_ranks(2, gas, sinks, 4, migrate_every=2)
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = 1e-2, 0.0
+    for _ in range(4):
+        dt, t = ctx.run(1, dt, t)
+    order = np.argsort(np.concatenate([p["state"]["gid"] for p in parts]))
+    assert parts[0]["dts"][-1] == dt and parts[1]["dts"][-1] == dt
+    for f in FIELDS:
+        merged = np.concatenate([p["state"][f] for p in parts])[order]
+        assert rel_err(merged, ctx.field(f)) <= 1e-11, f
+    ctx.close()
+
+
+def test_fortran_multi_gpu_host_one_rank(tmp_path):
+    """run_sph_hip_mg with one rank (RCCL communicator of size 1, id through the file) writes what run_sph_hip ... sph
+    writes: same dt decisions, same snapshot, byte for byte"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from summersph_amd import txtio
+    host = os.path.join(ROOT, "summersph_amd", "host")
+    if not os.path.exists(os.path.join(host, "run_sph_hip_mg")):
+        subprocess.run(["make", "-C", host], check=True, stdout=subprocess.DEVNULL)
+    g = load_golden("disc3000_traj")
+    icf = tmp_path / "ic.txt"
+    txtio.write_ic(str(icf), g["ic"])
+    a = subprocess.run([os.path.join(host, "run_sph_hip"), str(icf), "5", str(tmp_path / "one.txt"), "sph"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id.bin"), str(icf), "5", str(tmp_path / "mg.txt")],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    dts = lambda out: [l for l in out.splitlines() if l.startswith("dt ")]
+    assert dts(a.stdout) == dts(b.stdout) and len(dts(b.stdout)) == 6
+    assert [float(l.split()[2]) for l in dts(b.stdout)] == list(g["sph_dt_seq"])
+    assert (tmp_path / "one.txt").read_bytes() == (tmp_path / "mg.txt").read_bytes()
