@@ -164,6 +164,46 @@ def make_single_ctx(capi, ic, torch, variable, n, nngb, device, flags, ring=Fals
     return ctx
 
 
+class NativeSim:
+    """bench face of the native multi-GPU step loop (summersph_amd/halo.py): what DistSim offers the timed region"""
+
+    @classmethod
+    def create(cls, capi, dist, torch, local_rank, rank, world, flags, mine, sinks, bounds):
+        from summersph_amd import halo
+        uid = [halo.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        self, ok = cls(), 1
+        try:
+            self.ctx = capi.Context(device=local_rank, flags=flags)
+            self.h = halo.Halo.rccl(self.ctx, uid[0], rank, world)
+            self.h.selftest(4096)
+        except Exception as e:       # noqa: BLE001 -- e.g. two ranks on one GPU: RCCL refuses
+            ok = 0
+            print(f"[bench rank {rank}] native halo: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            return None
+        self.ctx.set_sinks(sinks)
+        self.h.set_slabs(bounds, 32)
+        self.h.upload(mine)
+        self.t, self.profile, self.phase_s = 0.0, False, {}
+        return self
+
+    def run(self, nsteps, dt):
+        dt, self.t = self.h.run(nsteps, dt, self.t)
+        return dt
+
+    @property
+    def n_owned(self):
+        return self.h.n_owned
+
+    @property
+    def stats(self):
+        s = self.h.stats()
+        return {"ghosts": s.ghosts, "migrated": s.migrated, "exchanges": s.exchanges, "migrations": s.migrations}
+
+
 def timed_run(ctx, torch, steps, warmup):
     dt, t = ctx.run(warmup, 1e-2, 0.0)
     ctx.timing(True); ctx.timing_reset()
@@ -199,6 +239,9 @@ def main():
                     "time per phase of the distributed step (perturbs the headline value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (host-staged messages)")
+    ap.add_argument("--halo", default="python", choices=["python", "native"],
+                    help="N>1 orchestrator: summersph_amd/dist.py over torch.distributed (default) or the native step loop "
+                    "of libsummersph_halo.so (own RCCL communicator, second HIP stream; fixed h without self-gravity)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -271,10 +314,18 @@ def main():
         mine = {k: v[sel] for k, v in gas.items()}
         mine["gid"] = np.nonzero(sel)[0]
         del rows, gas
-        be = HipBackend(local_rank, variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable else HipBackend(local_rank, flags=flags)
-        # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
-        sim = DistSim(be, mine, sinks, bounds, group=data_group, comm_device=None if data_backend == "nccl" else "cpu")
-        ctx = be.ctx
+        native = None
+        if args.halo == "native" and not variable and not args.self_gravity:
+            native = NativeSim.create(capi, dist, torch, local_rank, rank, world, flags, mine, sinks, bounds)
+            if native is None and rank == 0:
+                print("[bench] native halo unavailable on some rank; using dist.py", file=sys.stderr, flush=True)
+        if native is not None:
+            sim, ctx, data_backend = native, native.ctx, "rccl(native)"
+        else:
+            be = HipBackend(local_rank, variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable else HipBackend(local_rank, flags=flags)
+            # device tensors over RCCL (nccl); host-staged for the gloo rehearsal
+            sim = DistSim(be, mine, sinks, bounds, group=data_group, comm_device=None if data_backend == "nccl" else "cpu")
+            ctx = be.ctx
 
         def barrier():
             ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
