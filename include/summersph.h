@@ -254,6 +254,8 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     sph_density re-sorts everything.  SPH_ERR_NOMEM if the slots do not suffice.
  * sph_set_dt / sph_get_dt, sph_kick_devdt / sph_drift_devdt: dt and t held on the device
  *                     (sph_run's mechanism), so that a step needs no host round trip for them.
+ * sph_kick_drift_devdt / sph_kick_dt_candidate_dev: the same pairs of calls fused into one pass over the state each
+ *                     (kick + drift; closing kick + local dt candidate), bitwise the separate calls.
  * sph_dt_candidate_dev    local dt candidate ([F]:845-851 over owned particles) kept on the device.
  * sph_pack_partials_dev   d_out[0..3*64) = this GPU's partial sink accelerations (ax[64] ay[64]
  *                     az[64]), d_out[192] = its dt candidate, d_out[193..199) = the bounding box its owned particles
@@ -306,6 +308,8 @@ int sph_get_dt(sph_ctx *ctx, double *dt, double *t);
 int sph_kick_devdt(sph_ctx *ctx);
 int sph_drift_devdt(sph_ctx *ctx);
 int sph_dt_candidate_dev(sph_ctx *ctx);
+int sph_kick_drift_devdt(sph_ctx *ctx);
+int sph_kick_dt_candidate_dev(sph_ctx *ctx);
 int sph_pack_partials_dev(sph_ctx *ctx, double *d_out);
 int sph_apply_partials_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt);
 /* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */

@@ -977,6 +977,28 @@ int sph_get_dt(sph_ctx *c, double *dt, double *t) {
 int sph_kick_devdt(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_kick(c, 0.0, true); }
 int sph_drift_devdt(sph_ctx *c) { if (!c) return SPH_ERR_ARG; DeviceGuard g(c->device); return do_drift(c, 0.0, true); }
 
+// kick + drift in one pass over the state (bitwise sph_kick_devdt + sph_drift_devdt; what sph_step itself launches)
+int sph_kick_drift_devdt(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    if (!c->rates_valid) { c->err = "sph_kick_drift_devdt: rates are stale, call sph_forces first"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    Timed t(c, SPH_K_KICK);
+    API_HIP(launch_kick_drift(c));
+    c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; c->order_valid = false;
+    return SPH_OK;
+}
+
+// the closing kick + the local dt candidate in one pass (bitwise sph_kick_devdt + sph_dt_candidate_dev)
+int sph_kick_dt_candidate_dev(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    if (!c->rates_valid) { c->err = "sph_kick_dt_candidate_dev: rates are stale, call sph_forces first"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    Timed t(c, SPH_K_DT);
+    API_HIP(launch_kick_dt_candidate(c));
+    c->eos_valid = false;
+    return SPH_OK;
+}
+
 int sph_dt_candidate_dev(sph_ctx *c) {
     if (!c) return SPH_ERR_ARG;
     if (!c->rates_valid) { c->err = "sph_dt_candidate_dev: rates are stale"; return SPH_ERR_STATE; }

@@ -617,14 +617,12 @@ int evaluate(sph_halo *h) {
 
 int step(sph_halo *h) {
     if (int st = evaluate(h)) return st;
-    H_TRY(sph_kick_devdt(h->c));
-    H_TRY(sph_drift_devdt(h->c));
+    H_TRY(sph_kick_drift_devdt(h->c));
     h->pos_dirty = true;
     h->pred_for_drift = true;                   // the reduction above predicted where this drift takes everybody
     h->since_migrate++;
     if (int st = evaluate(h)) return st;
-    H_TRY(sph_kick_devdt(h->c));
-    H_TRY(sph_dt_candidate_dev(h->c));           // get_next_timestep's local part, [F]:845-851; reduced with the next evaluation
+    H_TRY(sph_kick_dt_candidate_dev(h->c));      // closing kick + get_next_timestep's local part, [F]:845-851; reduced with the next evaluation
     h->vel_dirty = true;
     h->dt_pending = true;
     return SPH_OK;

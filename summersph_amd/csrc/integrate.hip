@@ -231,6 +231,18 @@ hipError_t launch_kick_next_dt(sph_ctx *c, bool advance_t) {
     return hipGetLastError();
 }
 
+// multi-GPU: the closing kick + the LOCAL dt candidate in one pass (kick_dt_kernel), the rule itself after the rank reduction
+hipError_t launch_kick_dt_candidate(sph_ctx *c) {
+    KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
+               c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]};
+    int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
+    if (nb < 1) nb = 1;
+    kick_dt_kernel<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(a, c->f[SPH_F_C], c->p.h, c->n, c->d_dt, c->sink, c->ns, c->dt_part, c->orig,
+                                                               (int32_t)c->n_owned, c->variable ? c->f[SPH_F_H] : nullptr);
+    dt_candidate_only<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->d_dt);
+    return hipGetLastError();
+}
+
 hipError_t launch_next_dt(sph_ctx *c, bool advance_t) {
     int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
     if (nb < 1) nb = 1;

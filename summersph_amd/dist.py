@@ -210,6 +210,12 @@ class HipBackend:
     def dt_candidate_local(self):
         self.ctx.dt_candidate_dev()
 
+    def kick_drift(self):
+        self.ctx.kick_drift_devdt()          # one pass over the state, bitwise kick() + drift()
+
+    def kick_dt_candidate(self):
+        self.ctx.kick_dt_candidate_dev()     # bitwise kick() + dt_candidate_local()
+
     def pack_partials(self) -> torch.Tensor:
         out = torch.empty(PARTIALS, dtype=torch.float64, device=self.device)
         self.ctx.pack_partials_dev(out.data_ptr())
@@ -592,16 +598,22 @@ class DistSim:
         be = self.be
         self.evaluate()
         with self._phase("compute"):
-            be.kick()
-            be.drift()
+            if hasattr(be, "kick_drift"):
+                be.kick_drift()
+            else:
+                be.kick()
+                be.drift()
         self.pos_dirty = True
         self.sources_valid = False
         self.pred_for_drift = True       # the reduction of the evaluation above predicted where this drift takes everybody
         self.since_migrate += 1
         self.evaluate()
         with self._phase("compute"):
-            be.kick()
-            be.dt_candidate_local()          # get_next_timestep's local part, [F]:845-851; reduced with the next exchange
+            if hasattr(be, "kick_dt_candidate"):
+                be.kick_dt_candidate()
+            else:
+                be.kick()
+                be.dt_candidate_local()      # get_next_timestep's local part, [F]:845-851; reduced with the next exchange
         self.vel_dirty = True
         self.dt_pending = True
         if self.variable:

@@ -161,6 +161,39 @@ def test_rank_reduction_and_device_dt(capi, torch):
     ctx.close()
 
 
+def test_fused_kick_calls_are_bitwise_the_separate_ones(capi, torch):
+    """sph_kick_drift_devdt == sph_kick_devdt + sph_drift_devdt; sph_kick_dt_candidate_dev == sph_kick_devdt +
+    sph_dt_candidate_dev (state, sink velocities and the candidate).  All particles owned: ghost rho / rates are whatever
+    their owners last sent, which this test does not stage (the ghost protocol is covered by test_halo_gpu / test_dist_gpu)"""
+    gas, sinks = _disc(6000, 9)
+    res = []
+    for fused in (False, True):
+        ctx = _upload(capi, torch, gas, np.arange(6000))
+        ctx.set_sinks(sinks)
+        ctx.set_dt(0.013, 0.0)
+        ctx.density(); ctx.forces()
+        if fused:
+            ctx.kick_drift_devdt()
+        else:
+            ctx.kick_devdt(); ctx.drift_devdt()
+        ctx.density(); ctx.forces()
+        if fused:
+            ctx.kick_dt_candidate_dev()
+        else:
+            ctx.kick_devdt(); ctx.dt_candidate_dev()
+        out = {k: ctx.field(k) for k in "x y z vx vy vz u alpha".split()}
+        mine = torch.empty(199, dtype=torch.float64, device="cuda")
+        ctx.pack_partials_dev(mine.data_ptr())
+        ctx.synchronize()
+        out["cand"] = mine.cpu().numpy()[192:193]
+        s = ctx.get_sinks()
+        out["sx"], out["svx"] = s["x"], s["vx"]
+        res.append(out)
+        ctx.close()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_context_on_callers_stream(capi, torch):
     """sph_set_stream: the context runs on torch's current stream; device-pointer calls then need no host
     synchronisation to be ordered with torch kernels on that stream"""
