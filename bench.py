@@ -387,7 +387,7 @@ def main():
                           "pair_visits_per_s": pair_visits},
             "hbm_step": {"algorithmic_bytes_per_particle_step": bps, "achieved_GBs": bps * value / world / 1e9},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
-            "final_dt": dt, "device_bytes": st.device_bytes,
+            "final_dt": dt, "device_bytes": st.device_bytes, "list_builds": st.nlist_builds, "list_reflags": st.nlist_reflags,
         }
         copy_gbs = stream_copy_gbs(torch, local_rank)
         out["roofline"]["stream_copy_GBs"] = copy_gbs
@@ -409,6 +409,7 @@ def main():
                             f"(h 2.5..8, eta 1.2), grad-h, leaf-box neighbour rule, h update every step",
                 "value": args.n * args.steps / vel, "unit": "particle-steps/s", "ms_per_step": vel / args.steps * 1e3,
                 "mean_list_entries": vst.nlist_mean, "mean_wave_trips": vst.nlist_wave_mean, "max_list_entries": vst.nlist_max, "grid": list(vst.grid_dim),
+                "list_builds": vst.nlist_builds, "list_reflags": vst.nlist_reflags,
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in vkt.items()}, "final_dt": vdt,
                 "target_BASELINE_md": 1.0e7,
                 # dominant kernel: the list build (nlist_v_tiled): reads {x,y,z,h} + leaf box + id (68 B), writes the entries

@@ -94,6 +94,10 @@ typedef struct sph_params {
                                     the start-of-step evaluation, which sees the positions of the previous step's
                                     last evaluation (bitwise the same accelerations); OFF by default: the reference
                                     walks its tree in both evaluations ([F]:898,910) and the headline numbers do too */
+#define SPH_FLAG_NO_REFLAG 512   /* variable h: build the neighbour list anew also when only h changed since the last build
+                                    (start of a step, after calc_smoothing); by default that list is derived in place from the
+                                    list of the old lengths (varh.hip nlist_v_reflag: the same neighbour sets, entries in a
+                                    different order); A/B measurements                                */
 #define SPH_FLAG_REUSE_DENSITY 1 /* skip the density pass when positions and masses did not
                                     change since the last one (bitwise the same rho); OFF by
                                     default: the reference recomputes it, [F]:896,908 */
@@ -140,6 +144,8 @@ typedef struct sph_stats {
                                steady-state fixed-h step adds none (read-backs are taken one build late)       */
     double  lane_efficiency_forces; /* fixed h: list entries / lane-trips of the forces kernel in use (1 = no idle lanes):
                                        forces_q deals targets by list length, so this is not nlist_mean / nlist_wave_mean */
+    int64_t nlist_reflags;  /* variable h: list builds replaced by the re-flag pass (same positions, new h: the list of the
+                               new lengths derived from the list in place, entry for entry what a build would write) */
 } sph_stats;
 
 /* ---- life cycle: replaces init_kernel_table ([F]:55-79) and the tree (de)allocation

@@ -25,6 +25,7 @@ FLAG_ACCRETE_CULL = 32
 FLAG_SINK_CREATION = 64
 FLAG_NO_WHOLE_TILE = 128
 FLAG_REUSE_GRAVITY = 256
+FLAG_NO_REFLAG = 512
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
@@ -58,7 +59,7 @@ class Stats(C.Structure):
                 ("nlist_capacity", C.c_int32), ("nlist_max", C.c_int32), ("tile_fit_pct", C.c_int32), ("nlist_mean", C.c_double),
                 ("grid_builds", C.c_int64), ("nlist_builds", C.c_int64), ("density_passes", C.c_int64),
                 ("force_passes", C.c_int64), ("device_bytes", C.c_int64), ("nlist_wave_mean", C.c_double),
-                ("tile_fit_pct_forces", C.c_int32), ("host_syncs", C.c_int32), ("lane_efficiency_forces", C.c_double)]
+                ("tile_fit_pct_forces", C.c_int32), ("host_syncs", C.c_int32), ("lane_efficiency_forces", C.c_double), ("nlist_reflags", C.c_int64)]
 
 
 class SphError(RuntimeError):

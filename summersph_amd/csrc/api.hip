@@ -173,9 +173,13 @@ int do_density(sph_ctx *c) {
     if (!no_refresh && !c->grid_valid && c->variable && c->h_refresh_ok && c->order_valid && c->leaf_valid && c->n_slots == c->n) {
         // same positions, same particles, new h (calc_smoothing, Variable.f90:1152): the sorted order, the cell table and
         // the leaf cells stand; only what depends on h is redone -- and a self-gravity tree stays valid
-        API_TRY(varh_h_stats(c));
+        API_TRY(varh_h_stats(c, true));
         { Timed t(c, SPH_K_LEAF); API_TRY(varh_refresh_h(c)); }
-        { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
+        {   // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built
+            Timed t(c, SPH_K_NLIST);
+            if (varh_can_reflag(c)) API_TRY(varh_nlist_reflag(c));
+            else API_TRY(varh_nlist_build(c));
+        }
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
         c->grid_valid = true;
     }
@@ -492,6 +496,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     std::memset(c->h_pinned, 0, 640 * sizeof(double));
     if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 8 + 64, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 8, "flags")) != SPH_OK) return fail(st);
+    if (hipMemset(c->d_flags, 0, 8 * sizeof(int32_t)) != hipSuccess) return fail(SPH_ERR_HIP);
     if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->grav_tab, (size_t)p->nq + 1, "softening table")) != SPH_OK) return fail(st);
@@ -685,6 +690,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
     o->grid_builds = c->grid_builds; o->nlist_builds = c->nlist_builds;
     o->density_passes = c->density_passes; o->force_passes = c->force_passes;
     o->device_bytes = c->device_bytes;
+    o->nlist_reflags = c->nlist_reflags;
     if (c->n > 0 && c->nlist_builds > 0 && c->ncount && c->n <= c->cap) {      // counts of the last build
         DeviceGuard g(c->device);
         std::vector<int32_t> cnt((size_t)c->n);

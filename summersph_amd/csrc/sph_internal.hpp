@@ -160,6 +160,10 @@ struct sph_ctx {
     int32_t *plan_d = nullptr, *plan_f = nullptr;   // whole-tile kernels: the tile intervals of every workgroup (density / forces geometry), per list build
     int32_t *deal = nullptr;                        // forces_q: order of the targets within their workgroup (by list length)
     int32_t *ntail = nullptr;        // variable h: entries of the margin shell, stored from the end of the lane's column
+    // variable h, re-flag pass (varh.hip): the growth of h the list in place was built to survive, the growth measured
+    double vl_grow = 1.0, h_growth = 0.0;
+    bool list_has_margin = false;    // the list in place carries the margin shell calc_smoothing reads
+    int64_t nlist_reflags = 0;
     int32_t nl_max = 0; double nl_mean = 0.0;
 
     // kernel tables on the device
@@ -261,7 +265,9 @@ int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials);       // 
 int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, int32_t *d_keep_out, int64_t *removed);
 // variable-h path (varh.hip)
 hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
-int varh_h_stats(sph_ctx *c);          // h_max_glob, h_mean (one read-back)
+int varh_h_stats(sph_ctx *c, bool with_growth = false);   // h_max_glob, h_mean (+ h_growth against c->h_new): one read-back
+bool varh_can_reflag(const sph_ctx *c);
+int varh_nlist_reflag(sph_ctx *c);
 int varh_leaf_build(sph_ctx *c);       // leaf boxes of all particles for the current positions + h
 int varh_nlist_build(sph_ctx *c);
 int varh_refresh_h(sph_ctx *c);        // only h changed: prec, reaches and per-cell max h from the new h

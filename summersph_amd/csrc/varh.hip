@@ -54,26 +54,33 @@ __device__ __forceinline__ double wave_sumd(double v) {
 }
 
 // ---- h statistics -------------------------------------------------------------------------------
-__global__ __launch_bounds__(VBLOCK) void h_stats_partial(const double *__restrict__ h, int64_t n, double *__restrict__ part) {
-    __shared__ double sm[2][VBLOCK / WAVE];
-    double mx = 0.0, su = 0.0;
+// The re-flag pass (below) stands in for a list build at unchanged positions while no h has grown by more than this since
+// the build (shrinking only removes pairs; a measured optimum: 1.05 is used less often, 1.1 makes build and margin larger)
+constexpr double REFLAG_GROW = 1.07;
+
+// max h, sum h and -- with h_prev, the lengths the current list was built with -- the largest growth h / h_prev
+__global__ __launch_bounds__(VBLOCK) void h_stats_partial(const double *__restrict__ h, const double *__restrict__ h_prev, int64_t n,
+                                                          double *__restrict__ part) {
+    __shared__ double sm[3][VBLOCK / WAVE];
+    double mx = 0.0, su = 0.0, gr = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VBLOCK) {
         mx = fmax(mx, h[i]); su += h[i];
+        if (h_prev) gr = fmax(gr, h[i] / h_prev[i]);
     }
-    mx = wave_maxd(mx); su = wave_sumd(su);
-    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mx; sm[1][threadIdx.x >> 6] = su; }
+    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mx; sm[1][threadIdx.x >> 6] = su; sm[2][threadIdx.x >> 6] = gr; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < VBLOCK / WAVE; k++) { mx = fmax(mx, sm[0][k]); su += sm[1][k]; }
-        part[2 * blockIdx.x] = mx; part[2 * blockIdx.x + 1] = su;
+        for (int k = 1; k < VBLOCK / WAVE; k++) { mx = fmax(mx, sm[0][k]); su += sm[1][k]; gr = fmax(gr, sm[2][k]); }
+        part[3 * blockIdx.x] = mx; part[3 * blockIdx.x + 1] = su; part[3 * blockIdx.x + 2] = gr;
     }
 }
 
 __global__ void h_stats_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
-    double mx = 0.0, su = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) { mx = fmax(mx, part[2 * b]); su += part[2 * b + 1]; }
-    mx = wave_maxd(mx); su = wave_sumd(su);
-    if (threadIdx.x == 0) { out[0] = mx; out[1] = su; }
+    double mx = 0.0, su = 0.0, gr = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) { mx = fmax(mx, part[3 * b]); su += part[3 * b + 1]; gr = fmax(gr, part[3 * b + 2]); }
+    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr);
+    if (threadIdx.x == 0) { out[0] = mx; out[1] = su; out[2] = gr; }
 }
 
 // ---- octree leaf boxes ----------------------------------------------------------------------------
@@ -209,7 +216,32 @@ __device__ __forceinline__ double axis_gap2(double p, double lo, double e) {
 // scans its own cells out of LDS instead of gathering every candidate through the TA.
 constexpr int T_NV = 512;           // candidates per staged chunk: {x,y,z,h}, leaf box and id of each (68 B)
 
-__global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, double h_glob, const double4 *__restrict__ prec,
+// one chunk [cb, ce) of the sorted order into LDS: {x, y, z, (2 h_j)^2 (1 + 1e-12)}, the leaf box and the particle number.
+// Every test needs h_j only through that square, and x -> 4 x x c is monotone in floating point, so max(square_i, square_j)
+// is bitwise the square of max(h_i, h_j)
+__device__ __forceinline__ void stage_chunk(double4 *tile, double4 *tile_l, int32_t *tile_o, const double4 *__restrict__ prec,
+                                            const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
+                                            const int32_t *__restrict__ number, int cb, int ce) {
+    for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) {
+        double4 v = prec[cb + t];
+        v.w = 4.0 * v.w * v.w * (1.0 + 1e-12);
+        tile[t] = v; tile_l[t] = lrec[cb + t]; tile_o[t] = number ? number[orig[cb + t]] : orig[cb + t];
+    }
+}
+
+// the reference's rule for one candidate j of body i (both directions), written once for the build and the re-flag pass:
+// rij = i's walk reaches j's leaf; D = [V]:479 + kernel support of h_i; F = [V]:383 (the higher-numbered partner's walk decides)
+__device__ __forceinline__ void pair_flags(const double4 &pi, const double4 &li, int oi, double ri2, const double4 &pj, const double4 &lj,
+                                           int oj, double r2, bool &inD, bool &inF, bool &rij) {
+    rij = reaches(lj, pi.x, pi.y, pi.z);
+    inD = ((int)rij & (int)(r2 <= ri2)) != 0;
+    const bool rji = reaches(li, pj.x, pj.y, pj.z);
+    inF = ((int)(r2 <= fmax(ri2, pj.w)) & (int)(oi > oj ? rij : rji)) != 0;
+}
+
+// grow2 = (largest growth of any h the list shall survive)^2: candidates within 2 grow max(h_i, h_j) that count for nothing
+// now are kept in the margin shell too, so that nlist_v_reflag finds every pair a new h can switch on.
+__global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, double h_glob, double grow2, const double4 *__restrict__ prec,
                                                         const double4 *__restrict__ lrec, const int32_t *__restrict__ orig,
                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
@@ -219,7 +251,8 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     __shared__ double4 tile[T_NV], tile_l[T_NV];
     __shared__ int32_t tile_o[T_NV];
     __shared__ int s_lo[VBLOCK / WAVE], s_hi[VBLOCK / WAVE];
-    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    const int64_t blk = xcd_chunk(blockIdx.x, gridDim.x);
+    const int64_t i = blk * VBLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
     const bool live = i < n && orig[i] < n_owned;
@@ -237,6 +270,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     const double hi = pi.w, him = pi.w * H_MARGIN;
     const double rg = 2.0 * fmax(him, h_glob), rg2 = rg * rg * (1.0 + 1e-12);
     const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12), rim2 = 4.0 * him * him * (1.0 + 1e-12);
+    const double rig2 = grow2 * ri2;                      // (2 grow h_i)^2: the re-flag margin on the body's own side
     const int c1lo = max(cc[1] - R, 0), c1hi = min(cc[1] + R, d1 - 1);
     const int c0lo = max(cc[0] - R, 0), c0hi = min(cc[0] + R, d0 - 1);
     const int cap4 = cap >> 2;
@@ -265,13 +299,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
         for (int cb = lo; cb < hiv; cb += T_NV) {
             const int ce = min(cb + T_NV, hiv);
             __syncthreads();
-            for (int t = threadIdx.x; t < ce - cb; t += VBLOCK) {
-                // {x, y, z, (2 h_j)^2 (1 + 1e-12)}: every test below needs h_j only through this square, and x -> 4 x x c is
-                // monotone in floating point, so max(square_i, square_j) is bitwise the square of max(h_i, h_j)
-                double4 v = prec[cb + t];
-                v.w = 4.0 * v.w * v.w * (1.0 + 1e-12);
-                tile[t] = v; tile_l[t] = lrec[cb + t]; tile_o[t] = number ? number[orig[cb + t]] : orig[cb + t];
-            }
+            stage_chunk(tile, tile_l, tile_o, prec, lrec, orig, number, cb, ce);
             __syncthreads();
             if (!use2) continue;
             // per-lane walk over this lane's own columns and cells (lanes of different columns advance in
@@ -289,24 +317,23 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                     js = jn;
                     if (jb >= je) continue;
                     const double gap = g21 + axis_gap2(p[s0], g.org[s0] + c0 * e, e);
-                    if (gap > fmax(rim2, cell_hmax[row + c0])) continue;     // (2 max(1.1 h_i, hmax_C))^2 (1 + 1e-12)
+                    if (gap > fmax(rim2, grow2 * cell_hmax[row + c0])) continue;     // (2 max(1.1 h_i, grow hmax_C))^2 (1 + 1e-12)
                     for (int j = jb; j < je; j++) {
                         const double4 pj = tile[j - cb];
                         const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                         const double r2 = dx * dx + dy * dy + dz * dz;
-                        if (r2 <= fmax(rim2, pj.w) && j != (int)i) {
-                            const double4 lj = tile_l[j - cb];
-                            const bool rij = reaches(lj, pi.x, pi.y, pi.z);       // i's walk reaches j's leaf
-                            const bool inD = ((int)rij & (int)(r2 <= ri2)) != 0;     // [V]:479 + kernel support of h_i
-                            const bool rji = reaches(li, pj.x, pj.y, pj.z);       // j's walk reaches i's leaf
-                            const bool inF = ((int)(r2 <= fmax(ri2, pj.w)) & (int)(oi > tile_o[j - cb] ? rij : rji)) != 0;   // [V]:383
+                        if (r2 <= fmax(rim2, grow2 * pj.w) && j != (int)i) {
+                            bool inD, inF, rij;
+                            pair_flags(pi, li, oi, ri2, pj, tile_l[j - cb], tile_o[j - cb], r2, inD, inF, rij);
                             const int ent = (int32_t)((uint32_t)j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u) | (rij ? FLAG_R : 0u));
                             if (inD || inF) {
                                 const int q4 = cnt & 3;             // selects, not branches
                                 buf.x = q4 == 0 ? ent : buf.x; buf.y = q4 == 1 ? ent : buf.y; buf.z = q4 == 2 ? ent : buf.z; buf.w = q4 == 3 ? ent : buf.w;
                                 if (q4 == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
                                 cnt++;
-                            } else if (rij && r2 <= rim2) {                       // margin shell: only a trial h can need it
+                            } else if ((rij && r2 <= rim2) || r2 <= fmax(rig2, grow2 * pj.w)) {
+                                // margin shell: a trial h of calc_smoothing (reached, within 2.2 h_i) or a grown h (within
+                                // 2 grow max(h_i, h_j), reached or not: the reaches grow too) can need it
                                 const int q4 = tcnt & 3;
                                 tbuf.x = q4 == 0 ? ent : tbuf.x; tbuf.y = q4 == 1 ? ent : tbuf.y; tbuf.z = q4 == 2 ? ent : tbuf.z; tbuf.w = q4 == 3 ? ent : tbuf.w;
                                 if (q4 == 3 && tcnt < cap) mine[(size_t)(cap4 - 1 - (tcnt >> 2)) * 64] = tbuf;
@@ -330,6 +357,150 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     }
 }
 
+// Same positions, same sorted order, new h (calc_smoothing ran): the list of the new lengths out of the list of the old
+// ones, in place.  The D/F entries and the margin shell of a column are together every pair that a growth of any h by up
+// to `grow` can switch on, and every pair that was on.  Pass 1 re-evaluates the D/F entries where they stand (an entry
+// that counts for nothing any more keeps its slot without flags: a masked trip); pass 2 walks the margin rows from the
+// lowest row upwards and appends what the new lengths switch on behind the D/F entries -- writes never pass the reads,
+// because the build left rows(D/F) + rows(margin) <= rows of the column.  The wave walks its 64 columns in lock-step
+// like the evaluation kernels (rows two ahead, the candidate's record one entry ahead); the leaf box is fetched only for
+// candidates between the two kernel supports, the particle number only when the two walks disagree.
+// Both passes are software pipelines: the candidate's record is requested one entry ahead, classified when it arrives
+// (outside both supports: drop; inside both: D, F and R hold, see reflag_classify; in between: exact test), the leaf box and
+// the particle number of the in-between class are requested then and used one entry later -- no trip waits for a
+// memory round trip of its own.
+struct ReflagStage {          // an entry between classification and its flags
+    int j, cls;               // cls 0: nothing holds, 1: everything holds, 2: decide with the leaf box
+    bool d, rji;              // r <= 2 h_i;  j's walk reaches i's leaf
+    double4 lj;               // j's leaf box (cls 2)
+    int oj;                   // orig[j] (cls 2)
+};
+
+__device__ __forceinline__ void reflag_classify(const double4 &pi, const double4 &li, double ri2, bool act, int j, const double4 &pj_raw,
+                                                const double4 *__restrict__ lrec, const int32_t *__restrict__ orig, ReflagStage &st) {
+    const double pjw = 4.0 * pj_raw.w * pj_raw.w * (1.0 + 1e-12);          // as stage_chunk
+    const double dx = pi.x - pj_raw.x, dy = pi.y - pj_raw.y, dz = pi.z - pj_raw.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    // Inside both kernel supports (cls 1): a leaf box {|x - c| < 2 h + e/2} contains the sphere of radius 2 h around its own
+    // particle (which lies within e/2 of c), so both walks reach the other's leaf and D and F hold without looking at a
+    // box.  The 1 % keeps rounding at the sphere's surface out of this class (those pairs take the exact test).
+    st.cls = !act ? 0 : (r2 < 0.99 * fmin(ri2, pjw) ? 1 : (r2 <= fmax(ri2, pjw) ? 2 : 0));
+    st.j = j;
+    st.d = r2 <= ri2;
+    st.rji = reaches(li, pj_raw.x, pj_raw.y, pj_raw.z);
+    if (st.cls == 2) { st.lj = lrec[j]; st.oj = orig[j]; }
+}
+
+// the entry with its new flags (pair_flags' rule)
+__device__ __forceinline__ int reflag_finish(const double4 &pi, int oi, const ReflagStage &st, const int32_t *__restrict__ number) {
+    bool inD = st.cls == 1, inF = st.cls == 1, rij = st.cls == 1;
+    if (st.cls == 2) {
+        rij = reaches(st.lj, pi.x, pi.y, pi.z);
+        inD = ((int)rij & (int)st.d) != 0;                                  // [V]:479 + kernel support of h_i
+        inF = rij;
+        if (rij != st.rji) inF = oi > (number ? number[st.oj] : st.oj) ? rij : st.rji;      // [V]:383
+    }
+    return (int32_t)((uint32_t)st.j | (inD ? FLAG_D : 0u) | (inF ? FLAG_F : 0u) | (rij ? FLAG_R : 0u));
+}
+
+__global__ __launch_bounds__(VBLOCK) void nlist_v_reflag(const double4 *__restrict__ prec, const double4 *__restrict__ lrec,
+                                                         const int32_t *__restrict__ orig, int64_t n, int32_t n_owned, int32_t cap,
+                                                         int32_t *__restrict__ nlist, int32_t *__restrict__ ncount,
+                                                         const int32_t *__restrict__ ntail, int32_t *__restrict__ wave_max,
+                                                         const int32_t *__restrict__ number) {
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    if ((i & ~(int64_t)63) >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 6;
+    const bool live = i < n && orig[i] < n_owned;
+    const int self = i < n ? (int)i : (int)(n - 1);
+    const double4 pi = prec[self], li = lrec[self];
+    const int oi = number ? number[orig[self]] : orig[self];
+    const double ri2 = 4.0 * pi.w * pi.w * (1.0 + 1e-12);
+    const int cap4 = cap >> 2;
+    int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * cap4) * 64 + lane;
+    const int cnt_a = live ? min(ncount[i], cap) : 0, tcnt_a = live ? ntail[i] : 0;
+
+    // pass 1: the D/F entries, in place
+    int4 last = make_int4(0, 0, 0, 0);                      // the row that holds entry cnt_a (where pass 2 appends)
+    const int kmax = wave_max_i32(cnt_a);
+    if (kmax > 0) {
+        const int nrow = (kmax + 3) >> 2;
+        int4 qa = load_row(mine);
+        int4 qb = load_row(mine + (size_t)min(1, nrow - 1) * 64);
+        int e1 = 0 < cnt_a ? qa.x : self;
+        double4 p1 = prec[e1 & IDX_MASK];
+        ReflagStage st;
+        st.j = 0; st.cls = 0; st.d = false; st.rji = false; st.lj = li; st.oj = 0;
+        int4 outp = make_int4(0, 0, 0, 0);                  // the previous row, waiting for its fourth entry
+        for (int r = 0; r < nrow; r++) {
+            const int4 qc = load_row(mine + (size_t)min(r + 2, nrow - 1) * 64);
+            int4 out = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int k = 4 * r + v;
+                // the entry classified one trip ago gets its flags
+                if (v == 0) {
+                    if (r > 0) {
+                        outp.w = reflag_finish(pi, oi, st, number);
+                        if (4 * (r - 1) < cnt_a) mine[(size_t)(r - 1) * 64] = outp;
+                        if (r - 1 == (cnt_a >> 2)) last = outp;
+                    }
+                } else {
+                    const int ent = reflag_finish(pi, oi, st, number);
+                    if (v == 1) out.x = ent; else if (v == 2) out.y = ent; else out.z = ent;
+                }
+                // this trip's entry: its record has arrived; the next one's is requested
+                const int e0 = e1;
+                const double4 pj = p1;
+                if (k + 1 < cnt_a) {
+                    e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
+                    p1 = prec[e1 & IDX_MASK];
+                }
+                reflag_classify(pi, li, ri2, k < cnt_a, e0 & IDX_MASK, pj, lrec, orig, st);
+            }
+            outp = out;
+            qa = qb; qb = qc;
+        }
+        outp.w = reflag_finish(pi, oi, st, number);
+        if (4 * (nrow - 1) < cnt_a) mine[(size_t)(nrow - 1) * 64] = outp;
+        if (nrow - 1 == (cnt_a >> 2)) last = outp;
+    }
+    // pass 2: the margin shell, rows in ascending row index (= descending entry number); what the new lengths switch on is
+    // appended behind the D/F entries
+    int cnt = cnt_a;
+    int4 buf = last;
+    const int rows_t = (tcnt_a + 3) >> 2;
+    const int smax = wave_max_i32(rows_t);
+    int4 qn = rows_t > 0 ? mine[(size_t)(cap4 - rows_t) * 64] : make_int4(self, self, self, self);
+    for (int s = 0; s < smax; s++) {
+        const int tr = rows_t - 1 - s;                      // this lane's margin row (entries 4 tr .. 4 tr + 3), if it has one left
+        const bool has = tr >= 0;
+        const int4 q = qn;
+        if (tr >= 1) qn = mine[(size_t)(cap4 - tr) * 64];   // the next row (tr - 1) one step ahead; rows are never written before they are read
+        // the four records of the row in flight together, then the leaf boxes of those between the supports, then the flags
+        double4 pr[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) pr[v] = prec[(has && 4 * tr + v < tcnt_a) ? (comp4(q, v) & IDX_MASK) : self];
+        ReflagStage sv[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) reflag_classify(pi, li, ri2, has && 4 * tr + v < tcnt_a, comp4(q, v) & IDX_MASK, pr[v], lrec, orig, sv[v]);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int ent = reflag_finish(pi, oi, sv[v], number);
+            if ((uint32_t)ent & (FLAG_D | FLAG_F)) {
+                const int q4 = cnt & 3;
+                buf.x = q4 == 0 ? ent : buf.x; buf.y = q4 == 1 ? ent : buf.y; buf.z = q4 == 2 ? ent : buf.z; buf.w = q4 == 3 ? ent : buf.w;
+                if (q4 == 3) mine[(size_t)(cnt >> 2) * 64] = buf;
+                cnt++;
+            }
+        }
+    }
+    if (cnt > cnt_a && (cnt & 3) != 0) mine[(size_t)(cnt >> 2) * 64] = buf;
+    if (i < n) ncount[i] = live ? cnt : 0;
+    const int wm = wave_max_i32(live ? cnt : 0);
+    if (lane == 0) wave_max[w] = min(wm, cap);
+}
 
 // ---- the variable-h pair terms, written once (gather kernels and tile kernels call these) ---------------------------
 struct DensSumsV { double s1 = 0.0, s2 = 0.0; };     // sum m_j w(q),  sum m_j (q dw(q) - 3 w(q))
@@ -638,7 +809,8 @@ __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst 
                                                           double *__restrict__ rho, double *__restrict__ omega,
                                                           const int32_t *__restrict__ orig, int32_t n_owned,
                                                           const int32_t *__restrict__ nlist, int32_t cap,
-                                                          const int32_t *__restrict__ ncount, const int32_t *__restrict__ ntail) {
+                                                          const int32_t *__restrict__ ncount, const int32_t *__restrict__ ntail,
+                                                          int has_margin) {
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
     if (i >= n) return;
     const double h0 = h_old[i];
@@ -655,7 +827,7 @@ __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst 
         bool touched = false;
         while (((hn - old_len) / old_len) > pc.h_tol && hn < pc.h_iter_cap) {            // [V]:529
             old_len = hn;
-            if (hn <= H_MARGIN * h0) density_list(drec, mine, cap4, cnt, tcnt, w_tab, dw_tab, pc, pi, hn, r, om);
+            if (has_margin && hn <= H_MARGIN * h0) density_list(drec, mine, cap4, cnt, tcnt, w_tab, dw_tab, pc, pi, hn, r, om);
             else density_one(g, drec, lrec, cell_start, w_tab, dw_tab, pc, pi, hn, r, om);    // [V]:531-535
             touched = true;
             t = pc.eta / hn;
@@ -687,18 +859,21 @@ hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes) {
     return e;
 }
 
-int varh_h_stats(sph_ctx *c) {
+int varh_h_stats(sph_ctx *c, bool with_growth) {
     const int64_t n = std::max(c->n, c->n_slots);     // a pending ghost swap: every occupied slot (an upper bound on h)
+    c->h_growth = INFINITY;
     if (n == 0) { c->h_max_glob = c->h_mean = c->p.h; return SPH_OK; }
     const int nb = (int)std::min<int64_t>((n + VBLOCK - 1) / VBLOCK, 512);
     double *part = c->bbox_part;     // reuse the bbox partial buffer (>= 1024*6 doubles)
-    h_stats_partial<<<dim3(nb), dim3(VBLOCK), 0, c->stream>>>(c->f[SPH_F_H], n, part);
+    // with_growth: c->h_new holds the lengths the list in place was built with (launch_update_h swapped the two arrays)
+    h_stats_partial<<<dim3(nb), dim3(VBLOCK), 0, c->stream>>>(c->f[SPH_F_H], with_growth ? c->h_new : nullptr, n, part);
     h_stats_final<<<dim3(1), dim3(64), 0, c->stream>>>(part, nb, part + 2048);
     VH_CHECK(hipGetLastError());
-    VH_CHECK(hipMemcpyAsync(c->h_pinned + 28, part + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VH_CHECK(hipMemcpyAsync(c->h_pinned + 28, part + 2048, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     VH_CHECK(hipStreamSynchronize(c->stream));
     c->h_max_glob = c->h_pinned[28];
     c->h_mean = c->h_pinned[29] / (double)n;
+    if (with_growth) c->h_growth = c->h_pinned[30];
     if (!(c->h_max_glob > 0.0) || !std::isfinite(c->h_max_glob)) { c->err = "variable h: non-positive or non-finite smoothing length"; return SPH_ERR_ARG; }
     return SPH_OK;
 }
@@ -758,14 +933,17 @@ int varh_refresh_h(sph_ctx *c) {
 }
 
 int varh_nlist_build(sph_ctx *c) {
+    static const bool no_reflag_env = getenv("SPH_NO_REFLAG") != nullptr;      // A/B switches: always build, no re-flag margin
+    const bool no_reflag = no_reflag_env || (c->p.flags & SPH_FLAG_NO_REFLAG) != 0;
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
     const int R = std::max(1, (int)std::ceil(2.0 * H_MARGIN * c->h_max_glob * c->grid.inv_edge * (1.0 + 1e-9)));
     const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
+    const double grow = no_reflag ? 1.0 : REFLAG_GROW;
     for (int attempt = 0; attempt < 8; attempt++) {
         VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_v_tiled<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
-            c->grid, R, c->h_max_glob, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
+            c->grid, R, c->h_max_glob, grow * grow, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
             c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->d_flags,
             c->numbers_set ? c->number : nullptr);
         VH_CHECK(hipGetLastError());
@@ -773,13 +951,38 @@ int varh_nlist_build(sph_ctx *c) {
         VH_CHECK(hipStreamSynchronize(c->stream));
         const int32_t mx = *reinterpret_cast<int32_t *>(c->h_pinned + 9);
         c->nl_max = mx;
-        if (mx <= c->nl_cap) { c->nlist_builds++; return SPH_OK; }
+        if (mx <= c->nl_cap) {
+            c->nlist_builds++;
+            c->list_has_margin = true;
+            c->vl_grow = grow;
+            return SPH_OK;
+        }
         ctx_free(c, c->nlist);
         c->nl_cap = ((mx + mx / 8 + 8) + 3) & ~3;
         if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
     }
     c->err = "neighbour list did not converge";
     return SPH_ERR_STATE;
+}
+
+// can the list in place (built for the same positions and order with the lengths now in c->h_new) be re-flagged for
+// the new lengths?  needs its margin shell intact and no h grown beyond that margin (varh_h_stats(c, true) measured it)
+bool varh_can_reflag(const sph_ctx *c) {
+    return c->list_has_margin && c->vl_grow > 1.0 && c->h_growth <= c->vl_grow * (1.0 - 1e-12) && c->nl_cap > 0;
+}
+
+// the list of the new lengths out of the list of the old ones, in place (nlist_v_reflag); no read-back: a column cannot
+// outgrow its rows
+int varh_nlist_reflag(sph_ctx *c) {
+    const int64_t n = c->n;
+    if (n == 0) return SPH_OK;
+    nlist_v_reflag<<<dim3((unsigned)((n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
+        reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig, n, (int32_t)c->n_owned, c->nl_cap,
+        c->nlist, c->ncount, c->ntail, c->wave_max, c->numbers_set ? c->number : nullptr);
+    VH_CHECK(hipGetLastError());
+    c->list_has_margin = false;        // the margin rows may be overwritten: calc_smoothing falls back to its cell walk on this list
+    c->nlist_reflags++;
+    return SPH_OK;
 }
 
 hipError_t launch_density_v(sph_ctx *c, const PairConst &pc) {
@@ -814,7 +1017,7 @@ hipError_t launch_update_h(sph_ctx *c, const PairConst &pc) {
     update_h_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
         c->grid, pc, reinterpret_cast<const double4 *>(c->drec), reinterpret_cast<const double4 *>(c->lrec), c->cell_start,
         c->w_tab, c->dw_tab, c->n, c->f[SPH_F_H], c->h_new, c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->orig, (int32_t)c->n_owned,
-        c->nlist, c->nl_cap, c->ncount, c->ntail);
+        c->nlist, c->nl_cap, c->ncount, c->ntail, c->list_has_margin ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) std::swap(c->f[SPH_F_H], c->h_new);
     return e;

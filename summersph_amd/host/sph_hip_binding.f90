@@ -54,6 +54,7 @@ module sph_hip_binding
     real(c_double) :: nlist_wave_mean
     integer(c_int32_t) :: tile_fit_pct_forces, host_syncs
     real(c_double) :: lane_efficiency_forces
+    integer(c_int64_t) :: nlist_reflags
   end type sph_stats
 
   interface

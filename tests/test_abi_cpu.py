@@ -45,8 +45,8 @@ def test_abi_version_and_defaults(lib):
 def test_struct_sizes_match_header(lib):
     # sph_params: 3 doubles, 2 int32, 9 + 5 + 1 doubles
     assert ctypes.sizeof(capi.Params) == 3 * 8 + 2 * 4 + 15 * 8
-    # sph_stats: 2 int64, 3+1+1+1 int32, double, 4 int64, int64, double, 2 int32, double
-    assert ctypes.sizeof(capi.Stats) == 16 + 24 + 8 + 32 + 8 + 8 + 8 + 8
+    # sph_stats: 2 int64, 3+1+1+1 int32, double, 4 int64, int64, double, 2 int32, double, int64
+    assert ctypes.sizeof(capi.Stats) == 16 + 24 + 8 + 32 + 8 + 8 + 8 + 8 + 8
 
 
 def test_no_cpu_fallback(lib):

@@ -95,6 +95,58 @@ def test_disc_vs_oracle_larger(capi):
     ctx.close()
 
 
+def test_reflagged_list_vs_oracle(capi):
+    """after calc_smoothing only h is new: the list of the new lengths is derived in place from the list of the old ones
+    (nlist_v_reflag) once h has settled -- the evaluation on it against the CPU oracle, which searches afresh"""
+    from oracle import orc, orc_v
+    rows = ic.keplerian_disc_var(20000, seed=33)
+    gas, sinks = ic.split_rows(rows)
+    ctx = capi.Context(device=0, variable=True)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    o = orc_v.OracleV(gas, sinks, nthreads=orc.max_threads())
+    # the IC's guess of h relaxes: the first updates change it by more than the margin.  A re-flagged list has lost its
+    # margin shell, so without a drift in between the evaluations alternate between building and re-flagging: stop after
+    # one that built, the next one then re-flags
+    for it in range(10):
+        r0 = ctx.stats().nlist_reflags
+        ctx.density(); ctx.forces()
+        built = ctx.stats().nlist_reflags == r0
+        ctx.update_h()
+        o.evaluate(); o.update_h()
+        if built and it >= 4:
+            break
+    before = ctx.stats().nlist_reflags
+    ctx.density(); ctx.forces(); o.evaluate()
+    assert ctx.stats().nlist_reflags == before + 1
+    assert rel_err(ctx.field("h"), o.h) <= 1e-12
+    for f in ("rho", "omega", "ax", "ay", "az", "du", "dalpha"):
+        assert rel_err(ctx.field(f), getattr(o, f)) <= TOL, f
+    ctx.close()
+
+
+def test_reflag_equals_build_over_a_trajectory(capi):
+    """12 steps of a 60k disc with and without the re-flag pass: identical dt decisions, the same state to rounding (the
+    neighbour SETS are the same, the order of a few list entries is not), and the pass really ran"""
+    rows = ic.keplerian_disc_var(60000, seed=34)
+    gas, sinks = ic.split_rows(rows)
+    out = {}
+    for tag, flags in (("build", capi.FLAG_NO_REFLAG), ("reflag", 0)):
+        ctx = capi.Context(device=0, variable=True, flags=capi.FLAG_VARIABLE_H | flags)
+        ctx.upload(gas); ctx.set_sinks(sinks)
+        dts, t = [1e-2], 0.0
+        for _ in range(12):
+            dt, t = ctx.run(1, dts[-1], t)
+            dts.append(dt)
+        st = ctx.stats()
+        out[tag] = dict(dts=dts, reflags=st.nlist_reflags, builds=st.nlist_builds, **{f: ctx.field(f) for f in "x y z vx vy vz u alpha h rho".split()})
+        ctx.close()
+    assert out["build"]["reflags"] == 0 and out["reflag"]["reflags"] >= 4
+    assert out["reflag"]["builds"] + out["reflag"]["reflags"] == out["build"]["builds"]
+    assert out["build"]["dts"] == out["reflag"]["dts"]
+    for f in "x y z vx vy vz u alpha h rho".split():
+        assert rel_err(out["reflag"][f], out["build"][f]) <= 1e-13, f
+
+
 def test_full_simulate_trajectory_vs_reference_fixture(capi):
     """simulate() of the variable-h reference as it is: find_forces with the gas self-gravity (softening looked up
     with the particle's own h), calc_smoothing, sink accretion ([V]'s L1-distance rule) and the boundary cull"""
