@@ -30,6 +30,7 @@ namespace {
 
 constexpr int TB = 256;              // neighbour-list build: threads (= targets) per workgroup
 constexpr int T_NL = 512;            // ... and staged records per chunk (32 B each)
+constexpr int DEAL_BINS = 1024;      // counting sort of a group's list lengths (longer lists share the last bin)
 constexpr int WT_BS = 1024;          // density_wt: threads (= targets) per workgroup, one workgroup per CU
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int LDS_RESERVE = 1024;    // static LDS of the kernels (interval scratch) + slack
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                                                   const int32_t *__restrict__ cell_start, int64_t n, double rcut2, int32_t cap,
                                                   int4 *__restrict__ nlist4, int32_t *__restrict__ ncount,
                                                   int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
-                                                  const int32_t *__restrict__ orig, int32_t n_owned) {
+                                                  const int32_t *__restrict__ orig, int32_t n_owned, int2 *__restrict__ deal) {
     __shared__ double4 tile[T_NL];
     __shared__ int s_lo[4], s_hi[4];
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + threadIdx.x;
@@ -129,6 +130,37 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
         if (wm > 0) atomicMax(&flags[1], wm);
+    }
+    if (deal) {
+        // forces_q deals the 256 targets of this workgroup (= one of its groups) to its lanes in order of list length,
+        // longest first: deal[base + rank] = {index within the group, list length}, non-targets (-1) last.  A counting sort
+        // over the lengths in the tile's memory; among equal lengths the order is whatever the LDS atomics give, which no
+        // result depends on (a target's sums do not depend on the lanes that form them).
+        static_assert(TB == 256 && T_NL * sizeof(double4) >= 2 * DEAL_BINS * sizeof(int), "one group per workgroup; bins fit the tile");
+        int *hist = reinterpret_cast<int *>(tile), *start = hist + DEAL_BINS;
+        const int len = live ? min(cnt, cap) : -1;
+        const int bin = len < 0 ? 0 : min(len, DEAL_BINS - 2) + 1;
+        __syncthreads();                                  // the last chunk is no longer read
+        for (int k = threadIdx.x; k < DEAL_BINS; k += TB) hist[k] = 0;
+        __syncthreads();
+        const int pos = atomicAdd(&hist[bin], 1);
+        __syncthreads();
+        // start[b] = number of targets in bins above b; thread t owns bins 4 t .. 4 t + 3
+        constexpr int PER = DEAL_BINS / TB;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { loc[k] = hist[PER * threadIdx.x + k]; sum += loc[k]; }
+        int above = sum;                                  // inclusive suffix sum over the lanes of the wave (lane 63 highest bins)
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(above, o, 64); if (lane + o < 64) above += v; }
+        if (lane == 0) s_lo[threadIdx.x >> 6] = above;    // total of this wave
+        __syncthreads();
+        int higher = 0;
+        for (int q = (threadIdx.x >> 6) + 1; q < TB / 64; q++) higher += s_lo[q];
+        int run = above - sum + higher;                   // targets in bins above this thread's highest bin
+#pragma unroll
+        for (int k = PER - 1; k >= 0; k--) { start[PER * threadIdx.x + k] = run; run += loc[k]; }
+        __syncthreads();
+        deal[(int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + start[bin] + pos] = make_int2(threadIdx.x, len);
     }
 }
 
@@ -405,26 +437,6 @@ __global__ __launch_bounds__(BS) void wt_plan_kernel(GridDesc g, int32_t tcap, c
     }
 }
 
-// forces_q deals the T targets of a workgroup to its waves in order of list length (longest first): deal[base + rank] =
-// {the target's index within the group, its list length}.  rank = number of targets of the group with a longer list (ties: lower index
-// first).  Once per list build.
-template <int T>
-__global__ __launch_bounds__(T) void deal_kernel(int64_t n, const int32_t *__restrict__ ncount, const int32_t *__restrict__ orig, int32_t n_owned,
-                                                 int32_t cap, int2 *__restrict__ deal) {
-    __shared__ int s_cnt[T];
-    const int64_t base = (int64_t)blockIdx.x * T;
-    const int tl = threadIdx.x;
-    const int mine = (base + tl < n && orig[base + tl] < n_owned) ? min(ncount[base + tl], cap) : -1;      // -1: not a target
-    s_cnt[tl] = mine;
-    __syncthreads();
-    int before = 0;
-    for (int u = 0; u < T; u++) {
-        const int cu = s_cnt[u];
-        before += (cu > mine || (cu == mine && u < tl)) ? 1 : 0;
-    }
-    deal[base + before] = make_int2(tl, mine);
-}
-
 inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
 
 constexpr int FQ_T = 256;            // forces_q: targets per group
@@ -512,13 +524,9 @@ int nlist_build_tiled(sph_ctx *c) {
         TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
         nlist_tiled<<<dim3(tb_blocks(n)), dim3(TB), 0, c->stream>>>(c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start,
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
-                                                                    c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned);
+                                                                    c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned,
+                                                                    c->whole_tile ? reinterpret_cast<int2 *>(c->deal) : nullptr);
         TL_CHECK(hipGetLastError());
-        if (c->whole_tile) {
-            deal_kernel<256><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(n, c->ncount, c->orig, (int32_t)c->n_owned, c->nl_cap,
-                                                                                              reinterpret_cast<int2 *>(c->deal));
-            TL_CHECK(hipGetLastError());
-        }
         TL_CHECK(hipMemcpyAsync(slot, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         TL_CHECK(hipMemcpyAsync(slot + 1, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         TL_CHECK(hipEventRecord(c->ev_nl[p], c->stream));
