@@ -81,7 +81,8 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                                                   const int32_t *__restrict__ cell_start, int64_t n, double rcut2, int32_t cap,
                                                   int4 *__restrict__ nlist4, int32_t *__restrict__ ncount,
                                                   int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
-                                                  const int32_t *__restrict__ orig, int32_t n_owned, int2 *__restrict__ deal) {
+                                                  const int32_t *__restrict__ orig, int32_t n_owned, int2 *__restrict__ deal,
+                                                  int32_t *__restrict__ plan_f, int32_t tcap_f) {
     __shared__ double4 tile[T_NL];
     __shared__ int s_lo[4], s_hi[4];
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + threadIdx.x;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     int4 *mine = nlist4 + ((size_t)w * cap4) * 64 + lane;
     int cnt = 0;
     int4 buf = make_int4(0, 0, 0, 0);
+    int plo[3], plen[3];
 
 #pragma unroll
     for (int o2 = -1; o2 <= 1; o2++) {
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
         target_rows(g, cell_start, cc, live, o2, r);
         int lo, hi;
         block_interval(r, s_lo, s_hi, lo, hi);
+        plo[o2 + 1] = lo; plen[o2 + 1] = hi > lo ? hi - lo : 0;
         for (int cb = lo; cb < hi; cb += T_NL) {
             const int ce = min(cb + T_NL, hi);
             __syncthreads();
@@ -130,6 +133,13 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
         if (wm > 0) atomicMax(&flags[1], wm);
+    }
+    if (plan_f && threadIdx.x == 0) {
+        // the three intervals staged above are the tile of forces_q for this group of 256 targets: its plan for free
+        int32_t *p = plan_f + 8 * (size_t)xcd_chunk(blockIdx.x, gridDim.x);
+        const int need = plen[0] + plen[1] + plen[2];
+        p[0] = plo[0]; p[1] = plo[1]; p[2] = plo[2]; p[3] = plen[0]; p[4] = plen[1]; p[5] = plen[2]; p[6] = need; p[7] = 0;
+        if (need > tcap_f) atomicAdd(&flags[5], 1);
     }
     if (deal) {
         // forces_q deals the 256 targets of this workgroup (= one of its groups) to its lanes in order of list length,
@@ -418,23 +428,25 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
 // need, 0}.  Workgroups whose three intervals do not fit a tile of tcap records are counted in *misfit.  (Computing the
 // intervals inside the evaluation kernels cost them 18 dependent cell-table reads per thread, two wave reductions and a
 // barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
-template <int BS>
-__global__ __launch_bounds__(BS) void wt_plan_kernel(GridDesc g, int32_t tcap, const double4 *__restrict__ drec, const int32_t *__restrict__ cell_start,
-                                                     int64_t n, const int32_t *__restrict__ orig, int32_t n_owned, int32_t *__restrict__ plan,
-                                                     int32_t *__restrict__ misfit) {
-    __shared__ int s_lo[3 * (BS / 64)], s_hi[3 * (BS / 64)];
-    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
-    const bool live = i < n && orig[i] < n_owned;
-    const double4 pi = drec[i < n ? i : n - 1];
-    int cc[3];
-    cell_coords(g, pi.x, pi.y, pi.z, cc);
-    TileMap tm;
-    tile_map<BS / 64>(g, cell_start, cc, live, s_lo, s_hi, tm);
-    if (threadIdx.x == 0) {
-        int32_t *p = plan + 8 * (size_t)blockIdx.x;
-        p[0] = tm.lo[0]; p[1] = tm.lo[1]; p[2] = tm.lo[2]; p[3] = tm.len[0]; p[4] = tm.len[1]; p[5] = tm.len[2]; p[6] = tm.need; p[7] = 0;
-        if (tm.need > tcap) atomicAdd(misfit, 1);
+// the plan of a 1024-target group of density_wt = the union of the plans of its four 256-target groups (nlist_tiled writes those)
+__global__ __launch_bounds__(256) void plan_merge_kernel(int64_t ngroups_d, int64_t ngroups_f, const int32_t *__restrict__ plan_f, int32_t tcap_d,
+                                                         int32_t *__restrict__ plan_d, int32_t *__restrict__ misfit) {
+    const int64_t gd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gd >= ngroups_d) return;
+    int need = 0;
+    int32_t *p = plan_d + 8 * (size_t)gd;
+    for (int q = 0; q < 3; q++) {
+        int lo = 0x7fffffff, hi = 0;
+        for (int64_t gf = 4 * gd; gf < std::min<int64_t>(4 * gd + 4, ngroups_f); gf++) {
+            const int l = plan_f[8 * gf + q], len = plan_f[8 * gf + 3 + q];
+            if (len > 0) { lo = min(lo, l); hi = max(hi, l + len); }
+        }
+        const int len = hi > lo ? hi - lo : 0;
+        p[q] = lo; p[3 + q] = len;
+        need += len;
     }
+    p[6] = need; p[7] = 0;
+    if (need > tcap_d) atomicAdd(misfit, 1);
 }
 
 inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
@@ -456,16 +468,6 @@ int32_t tile_cap_q(int nq) {
     return (int32_t)((units * 8) / 49);
 }
 
-template <int BS>
-hipError_t plan_launch(sph_ctx *c, int32_t tcap, int32_t *plan, int32_t *misfit) {
-    wt_plan_kernel<BS><<<dim3((unsigned)((c->n + BS - 1) / BS)), dim3(BS), 0, c->stream>>>(
-        c->grid, tcap, reinterpret_cast<const double4 *>(c->drec), c->cell_start, c->n, c->orig, (int32_t)c->n_owned, plan, misfit);
-    return hipGetLastError();
-}
-
-hipError_t plan_bs(sph_ctx *c, int bs, int32_t tcap, int32_t *plan, int32_t *misfit) {
-    return bs == 1024 ? plan_launch<1024>(c, tcap, plan, misfit) : plan_launch<256>(c, tcap, plan, misfit);
-}
 
 }  // namespace
 
@@ -515,18 +517,21 @@ int nlist_build_tiled(sph_ctx *c) {
         if (4 * (int64_t)prev[0] > 3 * (int64_t)c->nl_cap) { const int st = regrow(prev[0] + prev[0] / 2 + 8); if (st != SPH_OK) return st; }
     }
     for (int attempt = 0; attempt < 8; attempt++) {
-        if (c->whole_tile) {
-            // the tile plans of both geometries; how many workgroups do not fit their tile: flags[4], flags[5]
-            TL_CHECK(hipMemsetAsync(c->d_flags + 4, 0, 2 * sizeof(int32_t), c->stream));
-            TL_CHECK(plan_bs(c, WT_BS, tile_cap(pc.nq, 4, true), c->plan_d, c->d_flags + 4));
-            TL_CHECK(plan_bs(c, FQ_T, tile_cap_q(pc.nq), c->plan_f, c->d_flags + 5));
-        }
-        TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
+        // flags[1]: longest list; flags[4], flags[5]: how many workgroups of density_wt / forces_q do not fit their tile
+        // (one fill: [2] and [3] belong to the sink code, which sets them before every use)
+        TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, 5 * sizeof(int32_t), c->stream));
         nlist_tiled<<<dim3(tb_blocks(n)), dim3(TB), 0, c->stream>>>(c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start,
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
                                                                     c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned,
-                                                                    c->whole_tile ? reinterpret_cast<int2 *>(c->deal) : nullptr);
+                                                                    c->whole_tile ? reinterpret_cast<int2 *>(c->deal) : nullptr,
+                                                                    c->whole_tile ? c->plan_f : nullptr, tile_cap_q(pc.nq));
         TL_CHECK(hipGetLastError());
+        if (c->whole_tile) {
+            const int64_t ngd = (n + WT_BS - 1) / WT_BS, ngf = (n + FQ_T - 1) / FQ_T;
+            plan_merge_kernel<<<dim3((unsigned)((ngd + 255) / 256)), dim3(256), 0, c->stream>>>(ngd, ngf, c->plan_f, tile_cap(pc.nq, 4, true), c->plan_d,
+                                                                                             c->d_flags + 4);
+            TL_CHECK(hipGetLastError());
+        }
         TL_CHECK(hipMemcpyAsync(slot, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         TL_CHECK(hipMemcpyAsync(slot + 1, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         TL_CHECK(hipEventRecord(c->ev_nl[p], c->stream));
