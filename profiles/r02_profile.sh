@@ -15,7 +15,7 @@ R=$GRAFT_REPO_ROOT
 for w in $wl; do
   case $w in
     fixed) args="--steps 5 --warmup 2 --no-cpu --no-variable" ;;
-    variable) args="--steps 5 --warmup 3 --no-cpu --mode variable" ;;
+    variable) args="--steps 6 --warmup 14 --no-cpu --mode variable" ;;   # past the first steps of the relaxing IC, where h jumps
     full) args="--steps 4 --warmup 2 --no-cpu --no-variable --full-simulate" ;;
   esac
   o=$R/gpurun_out/${tag}_$w
