@@ -204,16 +204,33 @@ class NativeSim:
         return {"ghosts": s.ghosts, "migrated": s.migrated, "exchanges": s.exchanges, "migrations": s.migrations}
 
 
-def timed_run(ctx, torch, steps, warmup):
+def timed_run(ctx, torch, steps, warmup, dominant=("forces",), breakdown=True):
+    """-> (seconds of the timed region, final dt, kernel table).  Inside the timed region only the `dominant` kernel
+    groups are bracketed by HIP events (the roofline's duration is measured live there; bracketing every group costs
+    ~4 % of a fixed-h step).  The per-group table comes from up to 10 further steps of the same trajectory with every
+    group bracketed -- outside the timed region -- in the format of Context.timing_get scaled to `steps` steps; the
+    dominant groups keep their totals from the timed region."""
     dt, t = ctx.run(warmup, 1e-2, 0.0)
-    ctx.timing(True); ctx.timing_reset()
+    ctx.timing(True, only=list(dominant)); ctx.timing_reset()
     ctx.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     dt, t = ctx.run(steps, dt, t)
     ctx.synchronize(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ctx.timing(False)
-    return el, dt
+    from summersph_amd import capi
+    table = {k: ctx.timing_get(k) for k in capi.KERNELS}
+    if breakdown:
+        bs = max(1, min(steps, 10))
+        ctx.timing_reset(); ctx.timing(True)
+        ctx.run(bs, dt, t)
+        ctx.synchronize()
+        ctx.timing(False)
+        for k in capi.KERNELS:
+            if k not in dominant:
+                ms, cnt = ctx.timing_get(k)
+                table[k] = (ms * steps / bs, int(round(cnt * steps / bs)))
+    return el, dt, table
 
 
 def main():
@@ -299,7 +316,7 @@ def main():
     sim = None
     if world == 1:
         ctx = make_single_ctx(capi, ic, torch, variable, args.n, args.nngb, local_rank, flags, ring=args.ic == "ring")
-        elapsed, dt = timed_run(ctx, torch, args.steps, args.warmup)
+        elapsed, dt, kt = timed_run(ctx, torch, args.steps, args.warmup)
         n_max = [args.n, 0]
     else:
         # weak scaling: the disc holds n x world particles (same surface density, larger radius); every rank
@@ -332,7 +349,7 @@ def main():
 
         dt = sim.run(args.warmup, 1e-2)
         sim.profile = args.dist_profile
-        ctx.timing(True); ctx.timing_reset()
+        ctx.timing(True, only=["forces"]); ctx.timing_reset()        # the other groups: untimed inside the region (see timed_run)
         barrier()
         t0 = time.perf_counter()
         dt = sim.run(args.steps, dt)
@@ -345,7 +362,8 @@ def main():
 
     if rank == 0:
         st = ctx.stats()
-        kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
+        if sim is not None:
+            kt = {k: ctx.timing_get(k) for k in capi.KERNELS}
         f_ms, f_cnt = kt["forces"]
         if sim is not None and not args.self_gravity:
             f_cnt = max(f_cnt // 2, 1)        # N > 1: one force pass = two launches (interior + boundary wavefronts)
@@ -401,9 +419,8 @@ def main():
         if world == 1 and not variable and not args.no_variable and args.ic == "disc" and not args.self_gravity:
             # BASELINE configs[2] on the same GPU, same step count
             vctx = make_single_ctx(capi, ic, torch, True, args.n, args.nngb, local_rank, 0)
-            vel, vdt = timed_run(vctx, torch, args.steps, args.warmup)
+            vel, vdt, vkt = timed_run(vctx, torch, args.steps, args.warmup, dominant=("nlist",))
             vst = vctx.stats()
-            vkt = {k: vctx.timing_get(k) for k in capi.KERNELS}
             out["variable_h"] = {
                 "workload": f"BASELINE configs[2]: uniform Keplerian disc, {args.n} particles, variable h "
                             f"(h 2.5..8, eta 1.2), grad-h, leaf-box neighbour rule, h update every step",
@@ -424,8 +441,7 @@ def main():
             fctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank,
                                    capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
             fsteps = max(2, args.steps // 2)
-            fel, fdt = timed_run(fctx, torch, fsteps, 1)
-            fkt = {k: fctx.timing_get(k) for k in capi.KERNELS}
+            fel, fdt, fkt = timed_run(fctx, torch, fsteps, 1, dominant=("grav_walk",))
             out["full_simulate"] = {
                 "workload": f"the headline disc with find_forces as the reference has it (Barnes-Hut gas self-gravity, "
                             f"theta 0.5) and the end-of-step sink accretion + boundary cull",
@@ -439,8 +455,7 @@ def main():
             # previous step's last walk (bitwise the same accelerations) -- reported beside the as-the-reference-runs number
             gctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank,
                                    capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL | capi.FLAG_REUSE_GRAVITY)
-            gel, gdt = timed_run(gctx, torch, fsteps, 1)
-            gkt = {k: gctx.timing_get(k) for k in capi.KERNELS}
+            gel, gdt, gkt = timed_run(gctx, torch, fsteps, 1, dominant=("gravity",), breakdown=False)
             out["full_simulate"]["reuse_gravity"] = {"value": args.n * fsteps / gel, "unit": "particle-steps/s", "ms_per_step": gel / fsteps * 1e3,
                                                       "gravity_ms_per_step": gkt["gravity"][0] / fsteps, "final_dt": gdt,
                                                       "note": "SPH_FLAG_REUSE_GRAVITY: one tree walk per step instead of two, same results bit for bit"}
@@ -453,9 +468,8 @@ def main():
                 g_s, s_s = ic.split_rows(rows_fn())
                 sctx = capi.Context(device=local_rank)
                 sctx.upload(g_s); sctx.set_sinks(s_s)
-                sel, sdt = timed_run(sctx, torch, max(2, args.steps // 2), 1)
+                sel, sdt, skt = timed_run(sctx, torch, max(2, args.steps // 2), 1)
                 sst = sctx.stats()
-                skt = {k: sctx.timing_get(k) for k in capi.KERNELS}
                 ss = max(2, args.steps // 2)
                 out["side_records"][tag] = {"value": n_s * ss / sel, "unit": "particle-steps/s", "ms_per_step": sel / ss * 1e3, "n": n_s,
                                             "mean_neighbours": sst.nlist_mean, "mean_wave_trips": sst.nlist_wave_mean,
@@ -468,7 +482,7 @@ def main():
                 # since the end of the last step): SPH_FLAG_REUSE_DENSITY keeps it.  Reported beside the headline,
                 # which runs every pass the reference runs.
                 rctx = make_single_ctx(capi, ic, torch, False, args.n, args.nngb, local_rank, flags | capi.FLAG_REUSE_DENSITY)
-                rel, rdt = timed_run(rctx, torch, args.steps, args.warmup)
+                rel, rdt, _ = timed_run(rctx, torch, args.steps, args.warmup, breakdown=False)
                 out["fixed_reuse_density"] = {"value": args.n * args.steps / rel, "unit": "particle-steps/s",
                                               "ms_per_step": rel / args.steps * 1e3, "final_dt": rdt,
                                               "note": "same results as the headline run, 1 density + 2 force passes per step"}

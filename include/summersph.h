@@ -268,6 +268,8 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     will have after the coming kick + drift (union over the three dt values the dt rule can
  *                     produce; NaN when the rates are stale): SPH_PARTIALS doubles, to be
  *                     all-gathered by the caller.
+ *                     sph_pack_partials_ex_dev(.., predict_box = 0) leaves the box out (NaN): it costs a pass over the
+ *                     particles and only a reduction that is followed by a drift has a reader for it.
  * sph_apply_partials_dev  sink accelerations = sum over the nranks gathered blocks (rank order);
  *                     apply_dt != 0: t += dt, then [F]:855-858 with the minimum candidate.
  * sph_set_boundary_boxes / sph_forces_part: forces in two launches so that the exchange of ghost fields overlaps
@@ -317,6 +319,7 @@ int sph_dt_candidate_dev(sph_ctx *ctx);
 int sph_kick_drift_devdt(sph_ctx *ctx);
 int sph_kick_dt_candidate_dev(sph_ctx *ctx);
 int sph_pack_partials_dev(sph_ctx *ctx, double *d_out);
+int sph_pack_partials_ex_dev(sph_ctx *ctx, double *d_out, int32_t predict_box);
 int sph_apply_partials_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt);
 /* P, c and the force gather records of ALL slots from the current rho, u, alpha, v          */
 int sph_refresh_eos(sph_ctx *ctx);
@@ -334,7 +337,9 @@ int sph_get_stats(sph_ctx *ctx, sph_stats *out);
  * after sph_density / sph_step): lo[3], hi[3].  Serves check_bounds ([F]:471-482) without a
  * download.                                                                              */
 int sph_get_bbox(sph_ctx *ctx, double *lo, double *hi);
-int sph_timing_enable(sph_ctx *ctx, int on);           /* HIP events around every kernel group */
+/* HIP events around kernel groups: on = 0 none, 1 every group, else a mask with bit (k + 1) set for sph_kernel_id k (timing
+ * one group costs two event records per launch of that group; timing all of them ~4 % of a fixed-h step)                */
+int sph_timing_enable(sph_ctx *ctx, int on);
 int sph_timing_reset(sph_ctx *ctx);
 int sph_timing_get(sph_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int sph_synchronize(sph_ctx *ctx);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_refresh_eos_ghosts", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
-    "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_pack_partials_dev",
+    "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_pack_partials_dev", "sph_pack_partials_ex_dev",
     "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev", "sph_set_numbers_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
@@ -142,6 +142,7 @@ def load():
     for f in ("sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.sph_pack_partials_dev.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sph_pack_partials_ex_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.sph_apply_partials_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.sph_set_boundary_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.sph_forces_part.argtypes = [C.c_void_p, C.c_int32]
@@ -361,8 +362,8 @@ class Context:
     def kick_dt_candidate_dev(self):
         self._ck(self.lib.sph_kick_dt_candidate_dev(self._h))
 
-    def pack_partials_dev(self, dev_ptr: int):
-        self._ck(self.lib.sph_pack_partials_dev(self._h, C.c_void_p(dev_ptr)))
+    def pack_partials_dev(self, dev_ptr: int, predict_box: bool = True):
+        self._ck(self.lib.sph_pack_partials_ex_dev(self._h, C.c_void_p(dev_ptr), 1 if predict_box else 0))
 
     def apply_partials_dev(self, dev_ptr: int, nranks: int, stride: int, apply_dt: bool):
         self._ck(self.lib.sph_apply_partials_dev(self._h, C.c_void_p(dev_ptr), nranks, stride, 1 if apply_dt else 0))
@@ -429,8 +430,10 @@ class Context:
         self._ck(self.lib.sph_get_bbox(self._h, lo, hi))
         return np.array(lo[:]), np.array(hi[:])
 
-    def timing(self, on: bool):
-        self._ck(self.lib.sph_timing_enable(self._h, 1 if on else 0))
+    def timing(self, on, only=None):
+        """HIP events around every kernel group (on=True), none (False), or only the groups named in `only`"""
+        mask = 0 if not on else (1 if only is None else sum(2 << KERNELS.index(k) for k in only))
+        self._ck(self.lib.sph_timing_enable(self._h, mask))
 
     def timing_reset(self):
         self._ck(self.lib.sph_timing_reset(self._h))

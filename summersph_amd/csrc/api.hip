@@ -143,7 +143,7 @@ void host_grav_table(int nq, std::vector<double> &g) {
 struct Timed {
     sph_ctx *c; int id; hipEvent_t e0 = nullptr, e1 = nullptr;
     Timed(sph_ctx *c_, int id_) : c(c_), id(id_) {
-        if (c->timing) {
+        if (c->timing & (1u << id)) {
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, c->stream);
         }
@@ -1014,13 +1014,15 @@ int sph_dt_candidate_dev(sph_ctx *c) {
     return SPH_OK;
 }
 
-int sph_pack_partials_dev(sph_ctx *c, double *d_out) {
+int sph_pack_partials_ex_dev(sph_ctx *c, double *d_out, int32_t predict_box) {
     if (!c || !d_out) return SPH_ERR_ARG;
     DeviceGuard g(c->device);
-    API_HIP(launch_pack_partials(c, d_out));
+    API_HIP(launch_pack_partials(c, d_out, predict_box != 0));
     if (c->own_stream) API_HIP(hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
+
+int sph_pack_partials_dev(sph_ctx *c, double *d_out) { return sph_pack_partials_ex_dev(c, d_out, 1); }
 
 int sph_apply_partials_dev(sph_ctx *c, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt) {
     if (!c || !d_all || nranks < 1 || stride < SPH_PARTIALS) return SPH_ERR_ARG;
@@ -1039,7 +1041,11 @@ int sph_get_bbox(sph_ctx *c, double *lo, double *hi) {
     return SPH_OK;
 }
 
-int sph_timing_enable(sph_ctx *c, int on) { if (!c) return SPH_ERR_ARG; c->timing = on != 0; return SPH_OK; }
+int sph_timing_enable(sph_ctx *c, int on) {
+    if (!c || on < 0) return SPH_ERR_ARG;
+    c->timing = on == 1 ? 0xffffffffu : ((unsigned)on >> 1);       // 1: every group; else bit k + 1 = group k
+    return SPH_OK;
+}
 
 int sph_timing_reset(sph_ctx *c) {
     if (!c) return SPH_ERR_ARG;

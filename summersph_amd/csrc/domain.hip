@@ -206,10 +206,10 @@ hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const in
     return hipGetLastError();
 }
 
-hipError_t launch_pack_partials(sph_ctx *c, double *d_out) {
+hipError_t launch_pack_partials(sph_ctx *c, double *d_out, bool predict_box) {
     pack_partials<<<dim3(1), dim3(256), 0, c->stream>>>(c->sink, c->d_dt, d_out);
     // [193, 199): the predicted bounding box of the owned particles after the coming drift (needs current rates)
-    if (c->rates_valid && c->n_slots == c->n) {
+    if (predict_box && c->rates_valid && c->n_slots == c->n) {
         const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->n + 255) / 256, PB_BLOCKS));
         pred_bbox_partial<<<dim3(nb), dim3(256), 0, c->stream>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], c->f[SPH_F_VX], c->f[SPH_F_VY],
                                                                  c->f[SPH_F_VZ], c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->orig,

@@ -561,9 +561,10 @@ int refresh_finish(sph_halo *h) {
 
 // sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied; the same message
 // carries every rank's predicted box after the coming kick + drift (dist.py _reduce)
-int reduce(sph_halo *h) {
+int reduce(sph_halo *h, bool before_drift) {
     H_HIP(h->part.need(SPH_PARTIALS * 8));
-    H_TRY(sph_pack_partials_dev(h->c, h->part.as<double>()));
+    // the predicted box costs a pass over the particles: only where a drift follows and other ranks read it
+    H_TRY(sph_pack_partials_ex_dev(h->c, h->part.as<double>(), (before_drift && h->P > 1) ? 1 : 0));
     if (h->P == 1) {
         H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, h->dt_pending ? 1 : 0));
         h->pred_valid = false;
@@ -577,14 +578,14 @@ int reduce(sph_halo *h) {
         H_HIP(hipEventRecord(h->e_pred, h->s1));
         H_HIP(hipStreamWaitEvent(h->s0, h->e_pred, 0));
         H_TRY(sph_apply_partials_dev(h->c, h->allpart.as<double>(), h->P, SPH_PARTIALS, h->dt_pending ? 1 : 0));
-        h->pred_valid = true;
+        h->pred_valid = before_drift;
     }
     h->dt_pending = false;
     return SPH_OK;
 }
 
 // one force evaluation: create_tree .. find_forces of the reference, [F]:894-898 (dist.py evaluate)
-int evaluate(sph_halo *h) {
+int evaluate(sph_halo *h, bool before_drift) {
     static const int32_t RHO[1] = {SPH_F_RHO};
     static const int32_t VEL[5] = {SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_ALPHA};
     const bool multi = h->P > 1;
@@ -612,16 +613,16 @@ int evaluate(sph_halo *h) {
     } else {
         H_TRY(sph_forces(h->c));
     }
-    return reduce(h);
+    return reduce(h, before_drift);
 }
 
 int step(sph_halo *h) {
-    if (int st = evaluate(h)) return st;
+    if (int st = evaluate(h, true)) return st;
     H_TRY(sph_kick_drift_devdt(h->c));
     h->pos_dirty = true;
     h->pred_for_drift = true;                   // the reduction above predicted where this drift takes everybody
     h->since_migrate++;
-    if (int st = evaluate(h)) return st;
+    if (int st = evaluate(h, false)) return st;           // a kick follows, no drift
     H_TRY(sph_kick_dt_candidate_dev(h->c));      // closing kick + get_next_timestep's local part, [F]:845-851; reduced with the next evaluation
     h->vel_dirty = true;
     h->dt_pending = true;
@@ -633,7 +634,7 @@ int finish_dt(sph_halo *h) {
     if (!h->dt_pending) return SPH_OK;
     H_HIP(h->part.need(SPH_PARTIALS * 8));
     H_HIP(h->row.need(SPH_PARTIALS * 8));
-    H_TRY(sph_pack_partials_dev(h->c, h->part.as<double>()));
+    H_TRY(sph_pack_partials_ex_dev(h->c, h->part.as<double>(), 0));
     if (h->P == 1) {
         H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, 1));
     } else {

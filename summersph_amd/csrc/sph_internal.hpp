@@ -193,7 +193,7 @@ struct sph_ctx {
     int64_t device_bytes = 0;
     std::unordered_map<void *, size_t> allocs;   // every device allocation of this context
     int32_t rank = 0, nranks = 1;   // multi-GPU: only rank 0 adds the sink-sink pair terms before the all-reduce
-    bool timing = false;
+    unsigned timing = 0;             // bit k: kernel group k is bracketed by HIP events
     sph::TimingSlot tslot[SPH_K_COUNT];
 };
 
@@ -240,7 +240,7 @@ hipError_t launch_kick_dt_candidate(sph_ctx *c);
 int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6);      // h_out6 != nullptr: synchronises
 int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts);
 int domain_replace_ghosts(sph_ctx *c, int64_t count, const double *d_vals);
-hipError_t launch_pack_partials(sph_ctx *c, double *d_out);
+hipError_t launch_pack_partials(sph_ctx *c, double *d_out, bool predict_box);
 hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const int64_t *d_numbers);
 hipError_t launch_apply_partials(sph_ctx *c, const double *d_all, int nranks, int stride, bool apply_dt);
 // LDS-tiled fixed-h kernels (tiled.hip; default)

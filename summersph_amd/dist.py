@@ -39,6 +39,7 @@ this orchestration on CPUs.  Nothing in this module computes physics.
 from __future__ import annotations
 
 import contextlib
+import inspect
 import time
 
 import numpy as np
@@ -216,9 +217,9 @@ class HipBackend:
     def kick_dt_candidate(self):
         self.ctx.kick_dt_candidate_dev()     # bitwise kick() + dt_candidate_local()
 
-    def pack_partials(self) -> torch.Tensor:
+    def pack_partials(self, predict_box: bool = True) -> torch.Tensor:
         out = torch.empty(PARTIALS, dtype=torch.float64, device=self.device)
-        self.ctx.pack_partials_dev(out.data_ptr())
+        self.ctx.pack_partials_dev(out.data_ptr(), predict_box)
         return out
 
     def apply_partials(self, allp: torch.Tensor, apply_dt: bool):
@@ -294,6 +295,7 @@ class DistSim:
         self.profile = False      # True: synchronise at phase boundaries and accumulate wall time per phase
         self.phase_s = {}
         self._gather_into = True  # all_gather_into_tensor until the backend refuses it
+        self._pack_has_switch = "predict_box" in inspect.signature(backend.pack_partials).parameters
         if self.P > 1:
             self.prime()
 
@@ -515,11 +517,14 @@ class DistSim:
     def _refresh_ghost_fields(self, names):
         self._refresh_ghost_finish(self._refresh_ghost_start(names))
 
-    def _reduce(self):
+    def _reduce(self, before_drift: bool = True):
         """sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied.  The same
         message carries every rank's PREDICTED bounding box after the coming kick + drift (the rates are known now), so
-        that the ghost exchange that follows the drift needs no exchange of bounding boxes of its own."""
-        allc = self._all_gather(self.be.pack_partials())
+        that the ghost exchange that follows the drift needs no exchange of bounding boxes of its own -- asked for only
+        where a drift follows and somebody reads it (it costs a pass over the particles)."""
+        predict = before_drift and self.P > 1 and not (self.gravity or self.variable)
+        part = self.be.pack_partials(predict) if self._pack_has_switch else self.be.pack_partials()
+        allc = self._all_gather(part)
         allp = allc.to(self.dev)
         self.be.apply_partials(allp, self.dt_pending)
         self.dt_pending = False
@@ -535,7 +540,7 @@ class DistSim:
             self._pred = self._pred_pinned
 
     # ---- the hot path, distributed -----------------------------------------------------------------
-    def evaluate(self):
+    def evaluate(self, before_drift: bool = True):
         """one force evaluation: create_tree..find_forces of the reference, [F]:894-898"""
         be = self.be
         if self.pos_dirty:
@@ -591,7 +596,7 @@ class DistSim:
             with self._phase("compute"):
                 be.forces()
         with self._phase("reduce"):
-            self._reduce()
+            self._reduce(before_drift)
 
     def _step(self):
         """one iteration of simulate()'s loop body, [F]:889-916, dt and t on the backend"""
@@ -607,7 +612,7 @@ class DistSim:
         self.sources_valid = False
         self.pred_for_drift = True       # the reduction of the evaluation above predicted where this drift takes everybody
         self.since_migrate += 1
-        self.evaluate()
+        self.evaluate(before_drift=False)     # a kick follows, no drift: nobody reads a predicted box
         with self._phase("compute"):
             if hasattr(be, "kick_dt_candidate"):
                 be.kick_dt_candidate()

@@ -23,7 +23,7 @@ module sph_hip_binding
   public :: sph_replace_ghosts_dev, sph_gather_fields_dev, sph_scatter_fields_dev, sph_refresh_eos_ghosts
   public :: sph_set_boundary_boxes, sph_forces_part, sph_set_dt, sph_get_dt, sph_kick_devdt, sph_drift_devdt
   public :: sph_kick_drift_devdt, sph_kick_dt_candidate_dev
-  public :: sph_dt_candidate_dev, sph_pack_partials_dev, sph_apply_partials_dev, sph_set_gravity_sources_dev
+  public :: sph_dt_candidate_dev, sph_pack_partials_dev, sph_pack_partials_ex_dev, sph_apply_partials_dev, sph_set_gravity_sources_dev
   public :: SPH_PARTIALS
   public :: c_message
 
@@ -354,6 +354,12 @@ module sph_hip_binding
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
     end function
+    integer(c_int) function sph_pack_partials_ex_dev(ctx, d_out, predict_box) bind(C, name='sph_pack_partials_ex_dev')
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: ctx, d_out
+      integer(c_int32_t), value :: predict_box
+    end function
+
     integer(c_int) function sph_pack_partials_dev(ctx, d_out) bind(C, name='sph_pack_partials_dev')
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx, d_out
