@@ -88,7 +88,7 @@ struct RcclTransport : Transport {
 };
 
 // the ranks are threads of one process on one device: a message is a device-to-device copy the receiver issues on its own
-// stream once the sender's data is ready (event), and nobody leaves a round before every copy out of its buffers is done
+// stream once the sender's data is ready (event); the sender's stream in turn waits for the copies out of its buffers
 struct Hub {
     int P;
     std::mutex m;
@@ -115,13 +115,15 @@ struct InprocTransport : Transport {
     Hub *hub = nullptr;
     int rank = 0;
     int finish(hipStream_t s, hipError_t e) {
-        // everybody passes the same barriers whatever happened, so a failing rank cannot strand the others
+        // everybody passes the same barriers whatever happened, so a failing rank cannot strand the others.  After the
+        // barrier every rank's copies are queued and marked (done): this rank's stream then waits for the peers' copies out of
+        // ITS buffers, so that -- as with RCCL -- the end of the operation on the stream means the send buffers are free.
+        // No rank waits on the host.
         if (e == hipSuccess) e = hipEventRecord(hub->done[rank], s);
         if (e != hipSuccess) hub->failed = true;
         hub->barrier();
-        for (int q = 0; q < hub->P && e == hipSuccess; q++) e = hipEventSynchronize(hub->done[q]);
-        hub->barrier();
-        if (e != hipSuccess) { err = std::string("in-process transport: ") + hipGetErrorString(e); return SPH_ERR_HIP; }
+        for (int q = 0; q < hub->P && e == hipSuccess; q++) e = hipStreamWaitEvent(s, hub->done[q], 0);
+        if (e != hipSuccess) { hub->failed = true; err = std::string("in-process transport: ") + hipGetErrorString(e); return SPH_ERR_HIP; }
         if (hub->failed) { err = "in-process transport: another rank failed"; return SPH_ERR_STATE; }
         return SPH_OK;
     }

@@ -117,6 +117,13 @@ class Halo:
         return cls._made(ctx, st, h, rank, nranks)
 
     @classmethod
+    def attach(cls, ctx, nccl_comm: int, comm_stream: int | None, rank: int, nranks: int):
+        """on a communicator (ncclComm_t as an integer) and, optionally, a HIP stream the caller owns"""
+        h = C.c_void_p()
+        st = load().sph_halo_attach(ctx._h, C.c_void_p(nccl_comm), C.c_void_p(comm_stream) if comm_stream else None, rank, nranks, C.byref(h))
+        return cls._made(ctx, st, h, rank, nranks)
+
+    @classmethod
     def inproc(cls, ctx, hub: Hub, rank: int, nranks: int):
         h = C.c_void_p()
         st = load().sph_halo_create_inproc(ctx._h, hub.ptr, rank, nranks, C.byref(h))

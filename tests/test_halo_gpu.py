@@ -122,6 +122,54 @@ def test_rccl_transport_single_rank():
     h.close(); ctx.close()
 
 
+def test_attach_to_a_callers_communicator_and_stream():
+    """sph_halo_attach: the ncclComm_t and the second hipStream_t belong to the caller (here: made with RCCL's and HIP's own
+    C entry points through ctypes, one rank); the loop must not destroy either"""
+    import ctypes as C
+    import torch
+    g = load_golden("disc3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    ctx = capi.Context(device=0)
+    halo.load()
+    rccl = C.CDLL("librccl.so.1")           # the copy already in the process (halo.load)
+
+    class Uid(C.Structure):
+        _fields_ = [("b", C.c_char * 128)]
+
+    uid = Uid()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    stream = torch.cuda.Stream(device=0)
+    h = halo.Halo.attach(ctx, comm.value, stream.cuda_stream, 0, 1)
+    h.selftest(50000)
+    ctx.set_sinks(sinks)
+    h.set_slabs(np.zeros(0), 0)
+    h.upload(gas)
+    dts, t = [1e-2], 0.0
+    for _ in range(5):
+        dt, t = h.run(1, dts[-1], t)
+        dts.append(dt)
+    assert dts == list(g["sph_dt_seq"])
+    st = h.download()
+    for f in FIELDS:
+        assert rel_err(st[f], g["sph_s5_" + f]) <= 1e-12, f
+    h.close()
+    # both are still the caller's: usable after the halo object is gone
+    x = torch.ones(8, device="cuda:0")
+    with torch.cuda.stream(stream):
+        y = (x * 2).sum()
+    stream.synchronize()
+    assert float(y) == 16.0
+    count = C.c_int(0)
+    rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert rccl.ncclCommCount(comm, C.byref(count)) == 0 and count.value == 1
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclCommDestroy(comm) == 0
+    ctx.close()
+
+
 def test_ring_two_ranks_viscosity():
     """the viscous, asymmetric workload (BASELINE configs[1] shape): 2 ranks against one context, 4 steps"""
     rows = ic.thin_ring(20000, seed=17)
