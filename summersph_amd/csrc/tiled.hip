@@ -221,8 +221,8 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
 __device__ __forceinline__ size_t poff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
 
 template <int BS>
-__global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, const int32_t *__restrict__ plan, const double4 *__restrict__ drec,
-                                                 const int32_t *__restrict__ nlist,
+__global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
+                                                 const double4 *__restrict__ drec, const int32_t *__restrict__ nlist,
                                                  int32_t cap, const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
                                                  const double *__restrict__ w_tab,
                                                  int64_t n, const double *__restrict__ u,
@@ -233,58 +233,64 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, con
     extern __shared__ double lds_dyn[];
     double *lds_w = lds_dyn;                                               // nq+1 doubles (padded to even)
     double4 *tile = reinterpret_cast<double4 *>(lds_dyn + ((pc.nq + 2) & ~1));
-    const int64_t group = xcd_chunk(blockIdx.x, gridDim.x);
-    const int64_t i = group * BS + threadIdx.x;
-    TileMap tm;
-    load_plan(plan, group, tm);
-    const bool fits = tm.need <= tcap;                 // workgroup-uniform
-    if (fits) stage_tile<BS, 4, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
+    // persistent, as forces_q: one workgroup per CU walks over groups of BS targets; the table once, the plan one group ahead;
+    // XCD x works on one contiguous eighth of the groups (its L2 then holds what neighbouring groups stage twice)
     for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_w[k] = w_tab[k];
+    const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
+    const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const int lane = threadIdx.x & 63;
-    const int64_t w = i >> 6;
-    const bool live = i < n && orig[i] < n_owned;
-    const int self = i < n ? (int)i : (int)(n - 1);
-    const double4 pi = drec[self];
-    __syncthreads();
-    if ((i & ~(int64_t)63) >= n) return;
-
-    const int cnt = live ? min(ncount[i], cap) : 0;
-    const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    double acc = 0.0;
-    if (fits && kmax > 0) {
-        // list rows as int4 (four entries), fetched two rows ahead with wave-uniform, unconditional loads
-        const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
-        const int nrow = (kmax + 3) >> 2;
-        int4 qa = load_row(mine4);
-        int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
-        double4 p1 = tile[0 < cnt ? tm.slot(qa.x) : 0];
-        for (int r = 0; r < nrow; r++) {
-            const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
+    int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
+    TileMap tm_next;
+    if (group < g_hi) load_plan(plan, group, tm_next);
+    for (; group < g_hi; group += per) {
+        const TileMap tm = tm_next;
+        if (group + per < g_hi) load_plan(plan, group + per, tm_next);
+        const int64_t i = group * BS + threadIdx.x;
+        const bool fits = tm.need <= tcap;                 // workgroup-uniform
+        __syncthreads();                                   // the previous group's tile is no longer read (first trip: the table is written)
+        if (fits) stage_tile<BS, 4, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
+        const int64_t w = i >> 6;
+        const bool live = i < n && orig[i] < n_owned;
+        const int self = i < n ? (int)i : (int)(n - 1);
+        const double4 pi = drec[self];
+        const int cnt = live ? min(ncount[i], cap) : 0;
+        const int kmax = (i & ~(int64_t)63) < n ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+        __syncthreads();
+        double acc = 0.0;
+        if (fits && kmax > 0) {
+            // list rows as int4 (four entries), fetched two rows ahead with wave-uniform, unconditional loads
+            const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
+            const int nrow = (kmax + 3) >> 2;
+            int4 qa = load_row(mine4);
+            int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
+            double4 p1 = tile[0 < cnt ? tm.slot(qa.x) : 0];
+            for (int r = 0; r < nrow; r++) {
+                const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll
-            for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the up to three trips past the
-                const int k = 4 * r + v;                  // wave's longest list are masked like any idle lane, and without
-                const double4 pj = p1;                    // the branch the pipeline registers rotate by renaming, not by moves
-                p1 = tile[k + 1 < cnt ? tm.slot(v < 3 ? comp4(qa, v + 1) : qb.x) : 0];
+                for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the up to three trips past the
+                    const int k = 4 * r + v;                  // wave's longest list are masked like any idle lane, and without
+                    const double4 pj = p1;                    // the branch the pipeline registers rotate by renaming, not by moves
+                    p1 = tile[k + 1 < cnt ? tm.slot(v < 3 ? comp4(qa, v + 1) : qb.x) : 0];
+                    density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                }
+                qa = qb; qb = qc;
+            }
+        } else if (!fits && kmax > 0) {
+            const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
+            int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
+            int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
+            double4 p1 = drec[j1];
+            for (int k = 0; k < kmax; k++) {
+                const double4 pj = p1;
+                j1 = j2;
+                if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
+                if (k + 1 < cnt) p1 = drec[j1];
                 density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
             }
-            qa = qb; qb = qc;
         }
-    } else if (!fits) {
-        const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
-        int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
-        int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
-        double4 p1 = drec[j1];
-        for (int k = 0; k < kmax; k++) {
-            const double4 pj = p1;
-            j1 = j2;
-            if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
-            if (k + 1 < cnt) p1 = drec[j1];
-            density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
-        }
+        if (live) density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
     }
-    if (!live) return;
-    density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
 }
 
 // forces, LPT lanes per target.  A workgroup of BS threads owns BS / LPT consecutive targets; the LPT lanes of a target take
@@ -570,8 +576,10 @@ hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + (size_t)tcap * sizeof(double4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    density_wt<WT_BS><<<dim3((unsigned)((c->n + WT_BS - 1) / WT_BS)), dim3(WT_BS), lds, c->stream>>>(
-        pc, tcap, c->plan_d, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
+    const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
+    const unsigned grid = (unsigned)std::min<int64_t>(ngroups, std::max(c->num_cus, 8));       // persistent: one workgroup per CU
+    density_wt<WT_BS><<<dim3(grid), dim3(WT_BS), lds, c->stream>>>(
+        pc, tcap, (int32_t)ngroups, c->plan_d, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
         c->w_tab, c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
         c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
     return hipGetLastError();
