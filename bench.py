@@ -29,6 +29,9 @@ Extra objects in the JSON line
                their own roofline object (dominant kernels: the variable-h list build, the gravity tree walk).
   cpu_baseline the CPU oracle (oracle/sph_oracle.c, OpenMP over the host cores) timed on a bounded
                sample of the same workload on this box (rank 0, N = 1 only).
+Timing: inside the timed region only the dominant kernel group is bracketed by HIP events (the roofline's duration);
+`kernel_ms_per_step` of the other groups comes from further steps of the same trajectory with every group bracketed, and
+`repeat_ms_per_step` repeats the K steps three more times (run-to-run spread) -- neither enters `value`.
 """
 import argparse
 import json
@@ -204,7 +207,7 @@ class NativeSim:
         return {"ghosts": s.ghosts, "migrated": s.migrated, "exchanges": s.exchanges, "migrations": s.migrations}
 
 
-def timed_run(ctx, torch, steps, warmup, dominant=("forces",), breakdown=True):
+def timed_run(ctx, torch, steps, warmup, dominant=("forces",), breakdown=True, repeats=0):
     """-> (seconds of the timed region, final dt, kernel table).  Inside the timed region only the `dominant` kernel
     groups are bracketed by HIP events (the roofline's duration is measured live there; bracketing every group costs
     ~4 % of a fixed-h step).  The per-group table comes from up to 10 further steps of the same trajectory with every
@@ -220,10 +223,23 @@ def timed_run(ctx, torch, steps, warmup, dominant=("forces",), breakdown=True):
     ctx.timing(False)
     from summersph_amd import capi
     table = {k: ctx.timing_get(k) for k in capi.KERNELS}
+    if repeats:
+        # run-to-run spread: the same number of steps again, `repeats` times, on the continuing trajectory (not part of `value`)
+        spread = []
+        for _ in range(repeats):
+            ctx.synchronize()
+            r0 = time.perf_counter()
+            dt_r, t = ctx.run(steps, dt if not spread else dt_r, t)
+            ctx.synchronize()
+            spread.append((time.perf_counter() - r0) / steps * 1e3)
+        table["_repeat_ms_per_step"] = spread
+        dt_b = dt_r
+    else:
+        dt_b = dt
     if breakdown:
         bs = max(1, min(steps, 10))
         ctx.timing_reset(); ctx.timing(True)
-        ctx.run(bs, dt, t)
+        ctx.run(bs, dt_b, t)
         ctx.synchronize()
         ctx.timing(False)
         for k in capi.KERNELS:
@@ -316,7 +332,8 @@ def main():
     sim = None
     if world == 1:
         ctx = make_single_ctx(capi, ic, torch, variable, args.n, args.nngb, local_rank, flags, ring=args.ic == "ring")
-        elapsed, dt, kt = timed_run(ctx, torch, args.steps, args.warmup)
+        elapsed, dt, kt = timed_run(ctx, torch, args.steps, args.warmup, repeats=3)
+        repeat_ms = kt.pop("_repeat_ms_per_step", None)
         n_max = [args.n, 0]
     else:
         # weak scaling: the disc holds n x world particles (same surface density, larger radius); every rank
@@ -392,6 +409,7 @@ def main():
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "repeat_ms_per_step": repeat_ms if world == 1 else None,      # the same K steps three more times: run-to-run spread
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "mode": args.mode, "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean, "mean_wave_trips": st.nlist_wave_mean,
                        "tile_fit_pct": st.tile_fit_pct, "tile_fit_pct_forces": st.tile_fit_pct_forces,
@@ -405,6 +423,8 @@ def main():
                           "pair_visits_per_s": pair_visits},
             "hbm_step": {"algorithmic_bytes_per_particle_step": bps, "achieved_GBs": bps * value / world / 1e9},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
+            "kernel_ms_note": "the dominant group (forces) timed inside the timed region; the others from further steps of the same "
+                              "trajectory with every group bracketed by HIP events (that costs ~4 % and stays out of `value`)",
             "final_dt": dt, "device_bytes": st.device_bytes, "list_builds": st.nlist_builds, "list_reflags": st.nlist_reflags,
         }
         copy_gbs = stream_copy_gbs(torch, local_rank)
