@@ -266,9 +266,19 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     bool any_mass = false;
     for (int k = 0; k < c->ns; k++) any_mass |= sm[k] > 0.0;
 
-    acc_keys<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, drec, n, c->mkeys, c->mvals);
-    size_t tmp = c->msort_tmp_bytes;
-    AC_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+    // the sorted path keys of the current grid build: left by the leaf-box build (variable h), copied from the self-gravity
+    // tree of the last evaluation (same positions, same root box, same key), or computed and sorted here (0.2 ms at 1e6)
+    if (c->path_keys_valid) {
+    } else if (c->gravity && c->tree_valid && !c->gx_src && c->g_keys_alt && c->g_vals_alt) {
+        AC_CHECK(hipMemcpyAsync(c->mkeys_alt, c->g_keys_alt, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        AC_CHECK(hipMemcpyAsync(c->mvals_alt, c->g_vals_alt, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        c->path_keys_valid = true;
+    } else {
+        acc_keys<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, drec, n, c->mkeys, c->mvals);
+        size_t tmp = c->msort_tmp_bytes;
+        AC_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
+        c->path_keys_valid = true;
+    }
     int32_t *keep = reinterpret_cast<int32_t *>(c->keys);          // the cell-key buffers are free between grid builds
     int32_t *pos = reinterpret_cast<int32_t *>(c->keys_alt);
     unsigned long long *accmask = reinterpret_cast<unsigned long long *>(c->scratch);
@@ -323,6 +333,7 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     AC_CHECK(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
     c->h_refresh_ok = false;
+    c->path_keys_valid = false;
     c->derived_kept = keep_derived;
     *removed = n - n_new;
     return SPH_OK;

@@ -188,6 +188,7 @@ int do_density(sph_ctx *c) {
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
         c->order_valid = true; c->derived_kept = false; c->grav_valid = false;
+        c->path_keys_valid = false;
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false; c->tree_valid = false;
         c->wave_class_valid = false; c->interior_done = false;
         if (c->variable) {

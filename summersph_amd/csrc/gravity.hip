@@ -508,10 +508,16 @@ int gravity_tree_build(sph_ctx *c) {
         const int st = global_keys_sorted(c);
         if (st != SPH_OK) return st;
     } else {
-        grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->g_keys, c->g_vals);
-        GR_CHECK2(hipGetLastError());
-        size_t tmp = c->g_sort_tmp_bytes;
-        GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
+        if (c->path_keys_valid && c->mkeys_alt && c->mvals_alt) {
+            // variable h: the leaf-box build of this grid build sorted the same keys (same positions, same root box)
+            GR_CHECK2(hipMemcpyAsync(c->g_keys_alt, c->mkeys_alt, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+            GR_CHECK2(hipMemcpyAsync(c->g_vals_alt, c->mvals_alt, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            grav_keys<<<dim3(gb), dim3(GB), 0, c->stream>>>(rb, drec, n, c->g_keys, c->g_vals);
+            GR_CHECK2(hipGetLastError());
+            size_t tmp = c->g_sort_tmp_bytes;
+            GR_CHECK2(rocprim::radix_sort_pairs(c->g_sort_tmp, tmp, c->g_keys, c->g_keys_alt, c->g_vals, c->g_vals_alt, (size_t)n, 0u, 63u, c->stream));
+        }
     }
     TreeArrays t = tree_arrays(c);
     leaf_data<<<dim3(gb), dim3(GB), 0, c->stream>>>(c->g_vals_alt, drec, (int)n, t);

@@ -105,6 +105,7 @@ struct sph_ctx {
     double *cell_hmax = nullptr;     // per cell: largest h of its particles
     double *h_new = nullptr;         // scratch for calc_smoothing
     double *leaf_half = nullptr;     // half edge of every slot's leaf cell (reach = 2 h + this)
+    bool path_keys_valid = false;    // mkeys_alt / mvals_alt hold the sorted octree path keys of the current grid build (root box: c->bbox)
     bool h_refresh_ok = false;       // the only thing newer than the grid is h (sph_update_h / an upload of h)
     bool leaf_valid = false;         // leaf cells match the current sorted order and (external) octree
     double h_max_glob = 0.0, h_mean = 0.0;

@@ -913,6 +913,7 @@ int varh_leaf_build(sph_ctx *c) {
         VH_CHECK(rocprim::radix_sort_pairs(c->msort_tmp, tmp, c->mkeys, c->mkeys_alt, c->mvals, c->mvals_alt, (size_t)n, 0u, 63u, c->stream));
         leaf_boxes<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, prec, reinterpret_cast<double4 *>(c->lrec), c->leaf_half);
         VH_CHECK(hipGetLastError());
+        c->path_keys_valid = true;           // the gravity tree and the accretion pass of this grid build take them from here
     }
     cell_hmax_kernel<<<dim3((unsigned)((c->grid.ncells + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), 0, c->stream>>>(
         c->cell_start, c->grid.ncells, prec, c->cell_hmax);
