@@ -205,10 +205,14 @@ __global__ __launch_bounds__(AB) void acc_sums_partial(int64_t n, int k, const u
 
 // [F]:497-508: new_mass, position and velocity become mass-weighted means, mass grows
 __global__ void acc_sink_update(int k, const double *__restrict__ part, int nb, double *__restrict__ sink) {
+    __shared__ double v[7];
+    if (threadIdx.x < 7) {                       // one lane per sum, each over the blocks in the same fixed order as ever
+        double r = 0.0;
+        for (int b = 0; b < nb; b++) r += part[(size_t)b * 7 + threadIdx.x];
+        v[threadIdx.x] = r;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < nb; b++)
-        for (int q = 0; q < 7; q++) v[q] += part[(size_t)b * 7 + q];
     const double m0 = sink[6 * MAX_SINKS + k];
     const double nm = m0 + v[0];
     for (int a = 0; a < 3; a++) {
