@@ -814,7 +814,7 @@ __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst 
     // Two phases.  Every lane takes the first Newton step of its own particle; most particles are done with it (h grew by
     // less than the tolerance, or shrank).  The ones that must re-evaluate rho -- a walk over their whole list -- are then
     // dealt densely to the lanes of the workgroup, so that the walks run in full wavefronts instead of in every wavefront
-    // for a third of its lanes (0.35 -> 0.2 ms per step on the bench disc).  A particle's result does not depend on the lane
+    // for a third of its lanes (0.49 -> 0.40 ms per step on the bench disc).  A particle's result does not depend on the lane
     // that computes it.
     __shared__ int s_list[VBLOCK];
     __shared__ int s_n;
