@@ -14,7 +14,8 @@ for f in glob.glob("gpurun_out/${tag}_hip/**/*hip_api_stats.csv", recursive=True
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 print("== rocprofv3 --hip-trace --stats of: python3 bench.py --steps 40 --warmup 5 --no-cpu --no-variable ==")
-print("(1 context created, upload, 5 warm-up + 40 timed steps of the fixed-h path, statistics read-back, stream-copy measurement)")
+print("(1 context created, upload, 5 warm-up + 40 timed steps of the fixed-h path, 3 x 40 steps of the spread measurement, 10 steps of the")
+print(" kernel breakdown, each bracketed by synchronisations; statistics read-back, stream-copy measurement: 175 steps in all)")
 print(f"{'HIP API':44s} {'calls':>8s} {'total_ms':>10s} {'avg_us':>10s}")
 for r in rows[:18]:
     print(f"{r['Name']:44s} {int(r['Calls']):8d} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f}")

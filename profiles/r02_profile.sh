@@ -27,3 +27,6 @@ for w in $wl; do
   echo "$w done"
 done
 cd $R && python3 profiles/make_limiters.py gpurun_out/${tag} $wl
+# what is kept: the summaries (copied next to the logs so that they come back from the GPU box); the raw passes are tens of MB
+cp profiles/r02_*_summary.txt profiles/r02_limiters.json gpurun_out/
+for w in $wl; do rm -rf gpurun_out/${tag}_${w}_kt gpurun_out/${tag}_${w}_fetch gpurun_out/${tag}_${w}_write gpurun_out/${tag}_${w}_sq gpurun_out/${tag}_${w}_ta; done
