@@ -6,7 +6,8 @@
  * -- without Python: the ghost exchange and the field refreshes are packed on the context's stream, travel as grouped
  * ncclSend / ncclRecv on a SECOND stream and are unpacked behind an event the boundary wavefronts wait for, while
  * the interior wavefronts (sph_forces_part(1)) run; the per-evaluation reduction (sink accelerations, dt candidate,
- * predicted boxes) is one ncclAllGather of SPH_PARTIALS doubles.  Fixed-h contexts without self-gravity (the headline path);
+ * predicted boxes) is one ncclAllGather of SPH_PARTIALS doubles; the ghost payload needs no size exchange (the room of a message is
+ * agreed from the last one, a header carries the count, overflows go a second round).  Fixed-h contexts without self-gravity (the headline path);
  * the octree paths stay with dist.py.
  *
  * The reference has no counterpart (single process); what this replaces on the reference side is the body of

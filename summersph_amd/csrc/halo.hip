@@ -243,6 +243,8 @@ struct sph_halo {
     double *pin_part = nullptr, *pin_boxes = nullptr;
     int64_t *pin_cnt = nullptr, *pin_row = nullptr;
     int64_t send_count[MAXP], ghost_first[MAXP], ghost_count[MAXP];
+    int64_t cap_send[MAXP], cap_recv[MAXP];   // ghost messages: particles the next message to / from a peer has room for (both sides agree)
+    double *pin_hdr = nullptr;               // pinned: headers out [0, P), headers in [P, 2P)
     bool refresh_pending = false;
     int refresh_nf = 0;
     int32_t refresh_fields[NF];
@@ -302,13 +304,14 @@ int common_init(sph_halo *h) {
     H_HIP(hipEventCreateWithFlags(&h->e_pred, hipEventDisableTiming));
     H_TRY(sph_set_stream(h->c, h->s0));
     H_TRY(sph_set_rank(h->c, h->rank, h->P));
-    const size_t nd = (size_t)h->P * (SPH_PARTIALS + 6) + (size_t)h->P * h->P + h->P + 64;
+    const size_t nd = (size_t)h->P * (SPH_PARTIALS + 6) + (size_t)h->P * h->P + h->P + 64 + 4 * (size_t)h->P;
     H_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin), nd * sizeof(double), hipHostMallocDefault));
     h->pin_part = h->pin;
     h->pin_boxes = h->pin_part + (size_t)h->P * SPH_PARTIALS;
     h->pin_cnt = reinterpret_cast<int64_t *>(h->pin_boxes + (size_t)h->P * 6);
     h->pin_row = h->pin_cnt + (size_t)h->P * h->P;
-    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_first[q] = 0; h->ghost_count[q] = 0; }
+    h->pin_hdr = reinterpret_cast<double *>(h->pin_row + h->P + 8);
+    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_first[q] = 0; h->ghost_count[q] = 0; h->cap_send[q] = 0; h->cap_recv[q] = 0; }
     h->edges.n = 0;
     return SPH_OK;
 }
@@ -345,6 +348,17 @@ int p2p(sph_halo *h, const int64_t *send_n, const int64_t *recv_n, int width) {
     h->st.exchanges++;
     return SPH_OK;
 }
+
+// one grouped round with explicit pointers and byte counts per peer
+int p2p_raw(sph_halo *h, const void *const *sp, const size_t *sb, void *const *rp, const size_t *rb) {
+    H_TR(h->tr->exchange(sp, sb, rp, rb, h->s1));
+    bool any = false;
+    for (int q = 0; q < h->P; q++) any |= sb[q] > 0 || rb[q] > 0;
+    if (any) h->st.exchanges++;                  // an empty group is not a round
+    return SPH_OK;
+}
+
+inline int64_t ghost_capacity(int64_t count) { return count + count / 4 + 256; }
 
 int ensure_reserve(sph_halo *h, int64_t n) {
     if (n + n / 8 + 32768 > h->reserved) {            // room for the ghost swaps; grows rarely (a re-allocation)
@@ -489,41 +503,74 @@ int exchange_ghosts(sph_halo *h) {
         h->st.host_waits++;
         for (int b = 0; b < npeers; b++) counts[peers[b]] = selc[b];
     }
-    std::vector<int64_t> cm((size_t)P * P);
-    if (int st = gather_counts(h, counts, cm.data())) return st;
-    int64_t rc[MAXP], total = 0;
-    for (int q = 0; q < P; q++) { rc[q] = q == h->rank ? 0 : cm[(size_t)q * P + h->rank]; total += rc[q]; }
-    // every ghost about to arrive lies inside its owner's box: particles farther than 2h from all of them cannot have a
-    // ghost neighbour (their forces do not wait for the ghost fields)
-    double bnd[MAXP * 6];
-    int nb = 0;
-    for (int q = 0; q < P; q++) if (rc[q] > 0) { for (int a = 0; a < 6; a++) bnd[nb * 6 + a] = boxes[(size_t)q * 6 + a]; nb++; }
-    H_TRY(sph_set_boundary_boxes(h->c, nb, bnd));
+    // The payload travels without a size exchange: both sides of a pair agree on the room the message has (cap_send here =
+    // cap_recv there, derived from the count of the last message between the two, 0 at first), the first two doubles say
+    // how many particles there are.  Round A: header + rows in that room.  Round B, for the pairs whose count did not fit
+    // (a first contact, a jump): the rows again at their exact size -- both sides know, the sender from its count, the
+    // receiver from the header.  Steady state: one round and one read-back of the headers, no collective.
+    bool touching[MAXP];
+    for (int q = 0; q < P; q++) touching[q] = false;
+    for (int b = 0; b < npeers; b++) touching[peers[b]] = true;
+    const void *sp[MAXP];
+    void *rp[MAXP];
+    size_t sb[MAXP], rb[MAXP];
+    for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
         const int64_t cnt = counts[q];
         h->send_count[q] = cnt;
-        if (cnt == 0) continue;
-        H_HIP(h->ids[q].need((size_t)cnt * 8));
-        H_HIP(h->sendb[q].need((size_t)cnt * (NF + 1) * 8));
-        H_TRY(sph_selected_ids_dev(h->c, b, cnt, h->ids[q].as<int64_t>()));
-        H_TRY(sph_gather_fields_dev(h->c, NF, STATE, cnt, h->ids[q].as<int64_t>(), h->sendb[q].as<double>()));
-    }
-    if (h->n_owned + total > h->reserved) {
-        h->err = "sph_halo: more ghosts than the reserved slots hold (n_owned + ghosts > n_owned * 5/4 + 65536)";
-        // the peers are already inside the exchange: take part in it before giving up, or they would wait forever
+        H_HIP(h->ids[q].need((size_t)std::max<int64_t>(cnt, 1) * 8));
+        H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * std::max(cnt, h->cap_send[q])) * 8));
+        H_HIP(h->recvb[q].need((size_t)(2 + NF * h->cap_recv[q]) * 8));
+        h->pin_hdr[2 * q] = (double)cnt; h->pin_hdr[2 * q + 1] = 0.0;
+        H_HIP(hipMemcpyAsync(h->sendb[q].p, h->pin_hdr + 2 * q, 16, hipMemcpyHostToDevice, h->s0));
+        if (cnt > 0) {
+            H_TRY(sph_selected_ids_dev(h->c, b, cnt, h->ids[q].as<int64_t>()));
+            H_TRY(sph_gather_fields_dev(h->c, NF, STATE, cnt, h->ids[q].as<int64_t>(), h->sendb[q].as<double>() + 2));
+        }
+        sp[q] = h->sendb[q].p; sb[q] = (size_t)(2 + NF * h->cap_send[q]) * 8;
+        rp[q] = h->recvb[q].p; rb[q] = (size_t)(2 + NF * h->cap_recv[q]) * 8;
     }
     if (int st = s0_then_s1(h)) return st;
-    if (int st = p2p(h, h->send_count, rc, NF)) return st;
+    if (int st = p2p_raw(h, sp, sb, rp, rb)) return st;
+    double *hdr_in = h->pin_hdr + 2 * P;
+    for (int b = 0; b < npeers; b++)
+        H_HIP(hipMemcpyAsync(hdr_in + peers[b], h->recvb[peers[b]].p, 8, hipMemcpyDeviceToHost, h->s1));
+    if (npeers > 0) if (int st = host_wait(h, h->s1)) return st;
+    int64_t rc[MAXP], total = 0, roff[MAXP];
+    for (int q = 0; q < P; q++) { rc[q] = touching[q] ? (int64_t)hdr_in[q] : 0; roff[q] = 2; total += rc[q]; }
+    // round B (every rank calls it, an empty group costs nothing): the pairs that did not fit
+    for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
+    for (int b = 0; b < npeers; b++) {
+        const int q = peers[b];
+        if (counts[q] > h->cap_send[q]) { sp[q] = h->sendb[q].as<double>() + 2; sb[q] = (size_t)NF * counts[q] * 8; }
+        if (rc[q] > h->cap_recv[q]) {
+            H_HIP(h->recvb[q].need((size_t)NF * rc[q] * 8));         // (re-allocation waits for the device: round A is complete)
+            rp[q] = h->recvb[q].p; rb[q] = (size_t)NF * rc[q] * 8;
+            roff[q] = 0;
+        }
+        h->cap_send[q] = ghost_capacity(counts[q]);
+        h->cap_recv[q] = ghost_capacity(rc[q]);
+    }
+    if (int st = p2p_raw(h, sp, sb, rp, rb)) return st;
     if (int st = s1_then_s0(h)) return st;
-    if (h->n_owned + total > h->reserved) return SPH_ERR_NOMEM;
+    // every ghost lies inside its owner's box: particles farther than 2h from all of them cannot have a ghost neighbour
+    // (their forces do not wait for the ghost fields)
+    double bnd[MAXP * 6];
+    int nb = 0;
+    for (int q = 0; q < P; q++) if (rc[q] > 0) { for (int a = 0; a < 6; a++) bnd[nb * 6 + a] = boxes[(size_t)q * 6 + a]; nb++; }
+    H_TRY(sph_set_boundary_boxes(h->c, nb, bnd));
+    if (h->n_owned + total > h->reserved) {
+        h->err = "sph_halo: more ghosts than the reserved slots hold (n_owned + ghosts > n_owned * 5/4 + 65536)";
+        return SPH_ERR_NOMEM;
+    }
     H_HIP(h->ghosts.need((size_t)std::max<int64_t>(total, 1) * NF * 8));
     int64_t first = h->n_owned, off = 0;
     for (int q = 0; q < P; q++) {
         h->ghost_first[q] = first;
         h->ghost_count[q] = rc[q];
         if (rc[q] > 0) {
-            gather_rows<<<blocks_for(rc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>(), rc[q], nullptr, rc[q], NF, h->ghosts.as<double>(), total, off);
+            gather_rows<<<blocks_for(rc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>() + roff[q], rc[q], nullptr, rc[q], NF, h->ghosts.as<double>(), total, off);
             H_HIP(hipGetLastError());
         }
         first += rc[q];
@@ -785,7 +832,7 @@ int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, co
     h->uploaded = true;
     h->pos_dirty = true; h->vel_dirty = false; h->dt_pending = false; h->pred_for_drift = false; h->pred_valid = false;
     h->since_migrate = 0;
-    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; }
+    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; h->cap_send[q] = 0; h->cap_recv[q] = 0; }
     return SPH_OK;
 }
 
