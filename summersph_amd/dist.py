@@ -273,6 +273,8 @@ class DistSim:
         self.dt_pending = False   # a local dt candidate waits for the next reduction
         self.since_migrate = 0
         self.send_idx = [None] * self.P      # per peer: original ids of my particles it holds as ghosts
+        self.cap_send = [0] * self.P         # per peer: particles the next ghost message to / from it has room for
+        self.cap_recv = [0] * self.P         # (both sides of a pair derive the same number from their last message)
         self.ghost_first = [0] * self.P      # per peer: first original id of its ghosts in my context
         self.ghost_count = [0] * self.P
         self.t = 0.0
@@ -447,19 +449,51 @@ class DistSim:
                 counts[q] = int(ids.numel())
                 if counts[q]:
                     self.send_idx[q] = ids
-        cm = self._all_gather(torch.tensor(counts, dtype=torch.int64)).cpu()
-        rc = [int(cm[q, self.rank]) for q in range(self.P)]
+        # The payload travels without a size exchange (as in csrc/halo.hip): both sides of a pair agree on the room of the
+        # next message (the count of their last message x 1.25 + 256; 0 at first), the first two doubles say how many
+        # particles it holds, the rows follow.  A count that does not fit is known to both sides -- to the sender from its
+        # count, to the receiver from the header -- and only those pairs exchange the rows again at their exact size.
+        nf = len(self.fields)
+        width = nf + (1 if self.variable else 0)            # variable h: + the global particle number of every ghost
+        rows = {}
+        msg = [None] * self.P
+        room = [0] * self.P
+        for q in peers:
+            idx = self.send_idx[q]
+            if idx is not None:
+                rows[q] = be.gather(self.fields, idx)
+                if self.variable:
+                    rows[q] = torch.cat([rows[q], self.gid[idx].to(torch.float64)[None, :]])
+            cap = self.cap_send[q]
+            m = torch.zeros((1, 2 + width * cap), dtype=torch.float64, device=self.dev)
+            m[0, 0] = counts[q]
+            if 0 < counts[q] <= cap:
+                m[0, 2:2 + width * counts[q]] = rows[q].reshape(-1)
+            msg[q] = m
+            room[q] = 2 + width * self.cap_recv[q]
+        got = self._p2p(msg, room, 1)
+        heads = torch.stack([got[q][0, 0] for q in peers]).cpu() if peers else torch.zeros(0)      # the one read-back
+        rc = [0] * self.P
+        for k, q in enumerate(peers):
+            rc[q] = int(heads[k])
+        again_send = [rows[q] if (q in peers and counts[q] > self.cap_send[q]) else None for q in range(self.P)]
+        again_recv = [rc[q] if (q in peers and rc[q] > self.cap_recv[q]) else 0 for q in range(self.P)]
+        if any(t is not None for t in again_send) or any(again_recv):
+            late = self._p2p(again_send, again_recv, width)
+        else:
+            late = [None] * self.P
+        recv = [None] * self.P
+        for q in peers:
+            if rc[q] == 0:
+                continue
+            recv[q] = late[q] if again_recv[q] else got[q][0, 2:2 + width * rc[q]].reshape(width, rc[q])
+        for q in peers:
+            self.cap_send[q] = counts[q] + counts[q] // 4 + 256
+            self.cap_recv[q] = rc[q] + rc[q] // 4 + 256
         # every ghost I am about to receive lies inside its owner's box: particles farther than 2h from all of them
         # cannot have a ghost neighbour (their forces do not wait for the ghost fields)
         senders = [q for q in range(self.P) if rc[q] > 0]
         be.set_boundary_boxes(boxes[senders] if senders else np.zeros((0, 6)))
-        nf = len(self.fields)
-        if self.variable:         # + the global particle number of every ghost
-            send = [torch.cat([be.gather(self.fields, idx), self.gid[idx].to(torch.float64)[None, :]]) if idx is not None else None
-                    for idx in self.send_idx]
-        else:
-            send = [be.gather(self.fields, idx) if idx is not None else None for idx in self.send_idx]
-        recv = self._p2p(send, rc, nf + (1 if self.variable else 0))
         first = self.n_owned
         parts = []
         for q in range(self.P):
