@@ -188,6 +188,58 @@ def test_ring_two_ranks_viscosity():
     ctx.close()
 
 
+def test_four_ranks_many_migrations_and_a_second_upload():
+    """4 ranks, ownership re-decided every step (a rotating disc crosses slab edges all the time), 8 steps; then the same halo
+    objects take a new particle set (sph_halo_upload again) and run it: the result of each must match a single context"""
+    rows = ic.keplerian_disc(24000, seed=41)
+    gas, sinks = ic.split_rows(rows)
+    rng = np.random.default_rng(5)
+    gas2 = {k: v.copy() for k, v in gas.items()}
+    gas2["vx"] = gas2["vx"] + rng.normal(0.0, 0.02, gas2["vx"].size)
+    world = 4
+    hub = halo.Hub(world)
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = capi.Context(device=0)
+            h = halo.Halo.inproc(ctx, hub, rank, world)
+            res = []
+            for g_ in (gas, gas2):
+                bounds = slab_bounds(g_["x"], world)
+                sel = np.searchsorted(bounds, g_["x"], side="right") == rank
+                mine = {k: v[sel] for k, v in g_.items()}
+                mine["gid"] = np.nonzero(sel)[0]
+                ctx.set_sinks(sinks)
+                h.set_slabs(bounds, 1)
+                h.upload(mine)
+                dt, t = h.run(8, 1e-2, 0.0)
+                res.append({"dt": dt, "state": h.download(), "stats": h.stats()})
+            out[rank] = res
+            h.close(); ctx.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    hub.close()
+    assert not errs, errs
+    for k, g_ in enumerate((gas, gas2)):
+        ctx = capi.Context(device=0)
+        ctx.upload(g_); ctx.set_sinks(sinks)
+        dt, t = ctx.run(8, 1e-2, 0.0)
+        gid = np.concatenate([out[r][k]["state"]["gid"] for r in range(world)])
+        assert np.array_equal(np.sort(gid), np.arange(gid.size))
+        order = np.argsort(gid)
+        assert all(out[r][k]["dt"] == dt for r in range(world))
+        for f in FIELDS:
+            merged = np.concatenate([out[r][k]["state"][f] for r in range(world)])[order]
+            assert rel_err(merged, ctx.field(f)) <= 1e-11, (k, f)
+        ctx.close()
+    assert out[0][1]["stats"].migrations >= 14 and out[0][1]["stats"].migrated > 0
+
+
 def test_fortran_multi_gpu_host_one_rank(tmp_path):
     """run_sph_hip_mg with one rank (RCCL communicator of size 1, id through the file) writes what run_sph_hip ... sph
     writes: same dt decisions, same snapshot, byte for byte"""
@@ -211,3 +263,14 @@ def test_fortran_multi_gpu_host_one_rank(tmp_path):
     assert dts(a.stdout) == dts(b.stdout) and len(dts(b.stdout)) == 6
     assert [float(l.split()[2]) for l in dts(b.stdout)] == list(g["sph_dt_seq"])
     assert (tmp_path / "one.txt").read_bytes() == (tmp_path / "mg.txt").read_bytes()
+    # the periodic saves through the collective gather: the same files as the single-GPU host writes
+    for sub, cmd in (("s1", [os.path.join(host, "run_sph_hip"), str(icf), "4", str(tmp_path / "s1" / "f.txt"), "sph", "saves", "tend=20"]),
+                     ("s2", [os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id2.bin"), str(icf), "4",
+                             str(tmp_path / "s2" / "f.txt"), "saves", "tend=20"])):
+        (tmp_path / sub).mkdir()
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path / sub, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(p.name for p in (tmp_path / "s1").glob("save*.txt"))
+    assert len(names) >= 2 and names == sorted(p.name for p in (tmp_path / "s2").glob("save*.txt"))
+    for nm in names:
+        assert (tmp_path / "s1" / nm).read_bytes() == (tmp_path / "s2" / nm).read_bytes(), nm
