@@ -121,8 +121,7 @@ __global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t 
     if (s > 0) cp = max(cp, common_levels(key, keys[s - 1]));
     if (s + 1 < n) cp = max(cp, common_levels(key, keys[s + 1]));
     // alone in the root box (n == 1): the root itself is the leaf; otherwise one level below the deepest
-    // node shared with another particle.  Keys identical over all 21 levels (closer than edge/2^21) would
-    // need deeper levels in the reference; the box is then taken at level 21.
+    // node shared with another particle
     const int level = n == 1 ? 0 : min(cp + 1, LEVELS);
     double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
     for (int l = 1; l <= level; l++) {
@@ -130,6 +129,36 @@ __global__ __launch_bounds__(VBLOCK) void leaf_boxes(RootBox rb, const uint64_t 
         const double q = 0.25 * size;
         cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
         size = size * 0.5;
+    }
+    if (cp == LEVELS && n > 1) {
+        // Keys identical over all 21 levels: somebody is closer than edge / 2^21 on every axis.  The reference goes on
+        // splitting (to depth 1000, [V]:8,203); so does this branch, from the positions themselves: the deepest level this
+        // particle shares with any member of the run of equal keys (a run is two or three particles), then its own path
+        // down to one level below.  (cx, cy, cz, size) is the common level-21 cell here.  Coincident points never
+        // separate: they end at level 1000 (the reference leaves them in a childless two-particle node its walks skip).
+        const double4 ps = prec[vals[s]];
+        int deepest = 0;
+        for (int dir = -1; dir <= 1; dir += 2)
+            for (int64_t t = s + dir; t >= 0 && t < n && keys[t] == key; t += dir) {
+                const double4 pt = prec[vals[t]];
+                double ax = cx, ay = cy, az = cz, as = size;
+                int extra = 0;
+                for (; extra < 1000 - LEVELS - 1; extra++) {
+                    const int cs = (ps.x > ax) | ((ps.y > ay) << 1) | ((ps.z > az) << 2);
+                    const int ct = (pt.x > ax) | ((pt.y > ay) << 1) | ((pt.z > az) << 2);
+                    if (cs != ct) break;
+                    const double q = 0.25 * as;
+                    ax = ax + ((cs & 1) ? q : -q); ay = ay + ((cs & 2) ? q : -q); az = az + ((cs & 4) ? q : -q);
+                    as = as * 0.5;
+                }
+                deepest = max(deepest, extra);
+            }
+        for (int l = 0; l <= deepest; l++) {              // levels 22 .. 22 + deepest of this particle's own path
+            const int ch = (ps.x > cx) | ((ps.y > cy) << 1) | ((ps.z > cz) << 2);
+            const double q = 0.25 * size;
+            cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+            size = size * 0.5;
+        }
     }
     const uint32_t slot = vals[s];
     const double h = prec[slot].w;

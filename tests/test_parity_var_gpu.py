@@ -95,6 +95,49 @@ def test_disc_vs_oracle_larger(capi):
     ctx.close()
 
 
+def test_pair_closer_than_the_key_resolution(capi):
+    """two particles closer than root_edge / 2^21 share their 63-bit path key; the reference splits on (to depth 1000) and
+    gives each a tiny leaf.  A third body placed just outside that tiny box -- but inside the box a level-21 leaf would have
+    -- tells the two rules apart: it must NOT count the pair in its density sum.  Checked against the CPU oracle, which
+    recurses like the reference."""
+    from oracle import orc, orc_v
+    rows = ic.keplerian_disc_var(4000, seed=35)
+    gas, sinks = ic.split_rows(rows)
+    pos = np.stack([gas[k] for k in "xyz"])
+    lo, hi = pos.min(1), pos.max(1)
+    root_c, root_s = (hi + lo) / 2.0, float((hi - lo).max())
+    e21 = root_s / 2.0 ** 21
+    j = int(np.argmin(np.abs(gas["x"] - 20.0) + np.abs(gas["y"]) + np.abs(gas["z"])))      # somewhere in the bulk
+    # the level-21 cell of j: replay the reference's splits
+    c, sz = root_c.copy(), root_s
+    for _ in range(21):
+        up = pos[:, j] > c
+        c = c + np.where(up, 0.25 * sz, -0.25 * sz)
+        sz *= 0.5
+    off = pos[0, j] - c[0]                               # j inside its cell along x, in (-e21/2, e21/2]
+    twin_dx = 0.05 * e21 * (-1.0 if off > 0 else 1.0)    # the twin stays in the same level-21 cell
+    hj = float(gas["h"][j])
+    sign = -1.0 if off > 0 else 1.0                      # probe on the side where the level-21 box reaches farther than the tiny one
+    room = e21 / 2.0 + abs(off)                          # how far that side of the level-21 box lies beyond the tiny one
+    probe_x = pos[0, j] + sign * (2.0 * hj + 0.2 * e21 + 0.25 * room)
+    add = {k: np.array([gas[k][j], gas[k][j]]) for k in gas}
+    add["x"] = np.array([pos[0, j] + twin_dx, probe_x])
+    add["h"] = np.array([hj, 1.3 * hj])
+    g2 = {k: np.concatenate([gas[k], add[k]]) for k in gas}
+    n = g2["x"].size
+    assert g2["x"].min() >= lo[0] and g2["x"].max() <= hi[0]              # the root box is unchanged
+    ctx = capi.Context(device=0, variable=True)
+    ctx.upload(g2); ctx.set_sinks(sinks)
+    o = orc_v.OracleV(g2, sinks, nthreads=orc.max_threads())
+    ctx.density(); ctx.forces(); o.evaluate()
+    # the oracle gave both twins leaves far smaller than a level-21 cell, and the probe does not see them
+    assert abs(o.ls[j]) <= e21 / 4 and abs(o.ls[n - 2]) <= e21 / 4
+    for f in ("rho", "omega", "ax", "ay", "az", "du"):
+        assert rel_err(ctx.field(f), getattr(o, f)) <= TOL, f
+    assert abs(ctx.field("rho")[n - 1] - o.rho[n - 1]) <= 1e-13 * o.rho[n - 1]
+    ctx.close()
+
+
 def test_reflagged_list_vs_oracle(capi):
     """after calc_smoothing only h is new: the list of the new lengths is derived in place from the list of the old ones
     (nlist_v_reflag) once h has settled -- the evaluation on it against the CPU oracle, which searches afresh"""
