@@ -536,7 +536,7 @@ int sph_ctx_destroy(sph_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     resolve_timing(c);
     free_particle_arrays(c);
-    ctx_free(c, c->cell_start); ctx_free(c, c->cell_fill); ctx_free(c, c->cell_hmax); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
+    ctx_free(c, c->cell_start); c->cell_fill = nullptr; ctx_free(c, c->cell_hmax); ctx_free(c, c->bbox_part); ctx_free(c, c->d_flags);
     ctx_free(c, c->grav_tab); ctx_free(c, c->sink_radius);
     ctx_free(c, c->w_tab); ctx_free(c, c->dw_tab); ctx_free(c, c->w_pair); ctx_free(c, c->dw_pair); ctx_free(c, c->sink); ctx_free(c, c->sink_part);
     ctx_free(c, c->dt_part); ctx_free(c, c->d_dt);

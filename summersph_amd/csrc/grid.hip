@@ -506,10 +506,10 @@ int grid_rebuild(sph_ctx *c) {
     c->grid = g;
 
     if (g.ncells + 2 > c->cell_cap) {
-        ctx_free(c, c->cell_start); ctx_free(c, c->cell_fill);
+        ctx_free(c, c->cell_start); c->cell_fill = nullptr;
         c->cell_cap = (g.ncells + 2) + (g.ncells + 2) / 4;
-        if (ctx_alloc(c, &c->cell_start, (size_t)c->cell_cap, "cell table") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
-        if (ctx_alloc(c, &c->cell_fill, (size_t)c->cell_cap, "cell cursors") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
+        // one allocation: the cell table and, right behind the part in use, the cursors of the counting sort (one fill zeroes both)
+        if (ctx_alloc(c, &c->cell_start, 2 * (size_t)c->cell_cap + 16, "cell table + cursors") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
         if (c->variable) {
             ctx_free(c, c->cell_hmax);
             if (ctx_alloc(c, &c->cell_hmax, (size_t)c->cell_cap, "cell hmax") != SPH_OK) { c->cell_cap = 0; return SPH_ERR_NOMEM; }
@@ -527,8 +527,9 @@ int grid_rebuild(sph_ctx *c) {
         counting = scan_tmp <= c->sort_tmp_bytes;
     }
     if (counting) {
-        GR_CHECK(hipMemsetAsync(c->cell_start, 0, sizeof(int32_t) * (size_t)(g.ncells + 2), st));
-        GR_CHECK(hipMemsetAsync(c->cell_fill, 0, sizeof(int32_t) * (size_t)(g.ncells + 1), st));
+        const size_t table = ((size_t)(g.ncells + 2) + 3) & ~(size_t)3, cursors = ((size_t)(g.ncells + 1) + 3) & ~(size_t)3;
+        c->cell_fill = c->cell_start + table;
+        GR_CHECK(hipMemsetAsync(c->cell_start, 0, sizeof(int32_t) * (table + cursors), st));        // multiples of 16 bytes: one fill kernel
         cell_keys_count<<<dim3(gbs), dim3(256), 0, st>>>(g, c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->keys, c->cell_start,
                                                         c->orig, (int32_t)c->n_owned, c->dead_below);
         GR_CHECK(hipGetLastError());

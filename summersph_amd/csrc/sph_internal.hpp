@@ -139,7 +139,7 @@ struct sph_ctx {
     uint32_t *keys = nullptr, *keys_alt = nullptr, *vals = nullptr, *vals_alt = nullptr;
     void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     int32_t *cell_start = nullptr; int64_t cell_cap = 0;
-    int32_t *cell_fill = nullptr;    // counting sort of the grid build: per-cell cursor
+    int32_t *cell_fill = nullptr;    // counting sort of the grid build: per-cell cursor (inside the cell_start allocation, behind the table)
     double *bbox_part = nullptr;     // per-block partial min/max
     double *h_pinned = nullptr;      // pinned host scratch (bbox[6], flags, dt, ...)
     int32_t *d_flags = nullptr;      // [0] nonfinite, [1] nlist max count
