@@ -12,7 +12,8 @@ are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line
 Workloads
   fixed (default, every N)   uniform disc, N x 1e6 gas particles + 1 sink, fixed h = 2.5: the [F] path
                              (BASELINE configs[1] shape at the metric's N = 1e6); shards over GPUs as
-                             x-slabs with ghost exchange + migration over RCCL (summersph_amd/dist.py).
+                             x-slabs with ghost exchange + migration over RCCL: the native step loop of
+                             libsummersph_halo.so where it applies (--halo auto), else summersph_amd/dist.py.
   variable (N = 1)           BASELINE configs[2]: 1e6 particles, per-particle h, grad-h terms, the
                              reference's leaf-box neighbour rule, h update every step.  At N = 1 the
                              default run measures it too and reports it as "variable_h" next to the
@@ -175,17 +176,28 @@ class NativeSim:
         from summersph_amd import halo
         uid = [halo.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        self, ok = cls(), 1
+        self = cls()
+
+        def agreed(ok):          # every rank must have succeeded: the next call is collective
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag[0]) == 1
+
+        ok = True
         try:
             self.ctx = capi.Context(device=local_rank, flags=flags)
             self.h = halo.Halo.rccl(self.ctx, uid[0], rank, world)
-            self.h.selftest(4096)
         except Exception as e:       # noqa: BLE001 -- e.g. two ranks on one GPU: RCCL refuses
-            ok = 0
+            ok = False
             print(f"[bench rank {rank}] native halo: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
+        if not agreed(ok):
+            return None
+        try:
+            self.h.selftest(4096)        # every rank sends to every rank and all-gathers, payloads checked
+        except Exception as e:       # noqa: BLE001
+            ok = False
+            print(f"[bench rank {rank}] native halo self-test: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        if not agreed(ok):
             return None
         self.ctx.set_sinks(sinks)
         self.h.set_slabs(bounds, 32)
@@ -272,9 +284,10 @@ def main():
                     "time per phase of the distributed step (perturbs the headline value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (host-staged messages)")
-    ap.add_argument("--halo", default="python", choices=["python", "native"],
-                    help="N>1 orchestrator: summersph_amd/dist.py over torch.distributed (default) or the native step loop "
-                    "of libsummersph_halo.so (own RCCL communicator, second HIP stream; fixed h without self-gravity)")
+    ap.add_argument("--halo", default="auto", choices=["auto", "python", "native"],
+                    help="N>1 orchestrator: the native step loop of libsummersph_halo.so (own RCCL communicator, second HIP "
+                    "stream; fixed h without self-gravity) or summersph_amd/dist.py over torch.distributed.  auto: native "
+                    "where it applies and RCCL is usable on every rank, else dist.py")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -349,7 +362,7 @@ def main():
         mine["gid"] = np.nonzero(sel)[0]
         del rows, gas
         native = None
-        if args.halo == "native" and not variable and not args.self_gravity:
+        if args.halo in ("auto", "native") and data_backend == "nccl" and not variable and not args.self_gravity:
             native = NativeSim.create(capi, dist, torch, local_rank, rank, world, flags, mine, sinks, bounds)
             if native is None and rank == 0:
                 print("[bench] native halo unavailable on some rank; using dist.py", file=sys.stderr, flush=True)
@@ -416,7 +429,9 @@ def main():
                        "max_neighbours": st.nlist_max, "grid": list(st.grid_dim), "reuse_density": bool(args.reuse_density),
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} x-slabs, ghost exchange + migration over "
-                                      + ("RCCL (torch.distributed nccl)" if data_backend == "nccl" else "host-staged gloo messages"),
+                                      + ({"nccl": "RCCL (summersph_amd/dist.py over torch.distributed nccl)",
+                                          "rccl(native)": "RCCL, native step loop (libsummersph_halo.so: grouped send/recv on a second HIP stream)"}
+                                         .get(data_backend, "host-staged gloo messages (summersph_amd/dist.py)")),
                        "max_owned_per_gpu": n_max[0], "max_ghosts_per_gpu": n_max[1], "rank0_slots": int(st.n)},
             "roofline": roof,
             "valu_fp64": {"achieved_tflops_est": flops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": flops / FP64_PEAK_TFLOPS,
