@@ -570,6 +570,15 @@ double forces_lane_efficiency(const std::vector<int32_t> &cnt) {
 }
 
 // ---- whole-tile kernels -------------------------------------------------------------------------------------
+// Workgroups of the persistent kernels: one per CU.  With several ranks four CUs stay free: a persistent workgroup holds the
+// whole register file of its CU (128 VGPRs x 16 waves), so nothing else starts beside it -- measured with the sinks' acceleration
+// on a second stream, which simply ran after forces_q -- and the send/receive kernels of the halo exchange are meant to run
+// beside the density pass and the interior wavefronts of the forces (1.6 % fewer CUs for the pair kernels).
+static unsigned persistent_grid(const sph_ctx *c, int64_t ngroups) {
+    const int cus = std::max(c->num_cus - (c->nranks > 1 ? 4 : 0), 8);
+    return (unsigned)std::min<int64_t>(ngroups, cus);
+}
+
 hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const int32_t tcap = tile_cap(pc.nq, 4, true);
@@ -577,7 +586,7 @@ hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
-    const unsigned grid = (unsigned)std::min<int64_t>(ngroups, std::max(c->num_cus, 8));       // persistent: one workgroup per CU
+    const unsigned grid = persistent_grid(c, ngroups);
     density_wt<WT_BS><<<dim3(grid), dim3(WT_BS), lds, c->stream>>>(
         pc, tcap, (int32_t)ngroups, c->plan_d, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
         c->w_tab, c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
@@ -593,7 +602,7 @@ static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     if (e != hipSuccess) return e;
     constexpr int T = BS / LPT;
     const int64_t ngroups = (c->n + T - 1) / T;
-    const unsigned grid = (unsigned)std::min<int64_t>(ngroups, std::max(c->num_cus, 8));       // persistent: one workgroup per CU
+    const unsigned grid = persistent_grid(c, ngroups);
     forces_q<BS, LPT><<<dim3(grid), dim3(BS), lds, c->stream>>>(
         pc, tcap, (int32_t)ngroups, c->plan_f, reinterpret_cast<const int2 *>(c->deal), c->frec, c->nlist, c->nl_cap, c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
