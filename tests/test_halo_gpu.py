@@ -274,3 +274,40 @@ def test_fortran_multi_gpu_host_one_rank(tmp_path):
     assert len(names) >= 2 and names == sorted(p.name for p in (tmp_path / "s2").glob("save*.txt"))
     for nm in names:
         assert (tmp_path / "s1" / nm).read_bytes() == (tmp_path / "s2" / nm).read_bytes(), nm
+
+
+def test_bench_glue_of_the_native_loop_one_rank():
+    """bench.py's NativeSim (what `bench.py --gpus N` runs by default) with a one-rank RCCL communicator and a stub for the
+    gloo control group: create -> self-test -> upload -> run -> stats, against sph_run"""
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class OneRank:                       # what NativeSim.create asks of torch.distributed
+        class ReduceOp:
+            MIN = None
+
+        @staticmethod
+        def broadcast_object_list(objs, src=0):
+            return None
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+
+    rows = ic.keplerian_disc(20000, seed=43)
+    gas, sinks = ic.split_rows(rows)
+    mine = dict(gas); mine["gid"] = np.arange(gas["x"].size)
+    sim = bench.NativeSim.create(capi, OneRank, torch, 0, 0, 1, 0, mine, sinks, np.zeros(0))
+    assert sim is not None
+    dt = sim.run(3, 1e-2)
+    dt = sim.run(4, dt)
+    assert sim.n_owned == gas["x"].size and sim.stats["ghosts"] == 0
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    d2, t2 = ctx.run(7, 1e-2, 0.0)
+    assert dt == d2 and sim.t == t2
+    assert np.array_equal(sim.h.download()["x"], ctx.field("x"))
+    sim.h.close(); sim.ctx.close(); ctx.close()
