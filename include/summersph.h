@@ -255,6 +255,11 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     (lo_hi, synchronises) and/or to device memory (d_lo_hi).
  * sph_select_boxes    for each of nbox boxes {lo xyz, hi xyz}: the owned particles inside, ascending
  *                     original id; counts to the host; ids fetched with sph_selected_ids_dev.
+ * sph_select_boxes_async  the same selection without the wait: the counts stay on the device (and travel to pinned memory
+ *                     behind the selection); sph_gather_selected_dev packs a selection whose size only the device knows:
+ *                     d_out[0] = count, d_out[1] = 0, then d_out[2 + f*count + k] -- if count <= capacity, else the header
+ *                     alone; sph_selected_counts hands the counts over once the caller has synchronised with whatever
+ *                     followed the selection on the context's stream (it does not wait itself).
  * sph_replace_ghosts_dev  drop the current ghosts and append `count` new ones (d_state[f*count + k],
  *                     f = x y z vx vy vz u m alpha); owned particles stay where they are, the next
  *                     sph_density re-sorts everything.  SPH_ERR_NOMEM if the slots do not suffice.
@@ -310,6 +315,9 @@ int sph_reserve(sph_ctx *ctx, int64_t n_slots);
 int sph_owned_bbox(sph_ctx *ctx, double *lo_hi, double *d_lo_hi);
 int sph_select_boxes(sph_ctx *ctx, int32_t nbox, const double *boxes, int64_t *counts);
 int sph_selected_ids_dev(sph_ctx *ctx, int32_t box, int64_t count, int64_t *d_ids);
+int sph_select_boxes_async(sph_ctx *ctx, int32_t nbox, const double *boxes);
+int sph_selected_counts(sph_ctx *ctx, int32_t nbox, int64_t *counts);
+int sph_gather_selected_dev(sph_ctx *ctx, int32_t box, int32_t nf, const int32_t *fields, int64_t capacity, double *d_out);
 int sph_replace_ghosts_dev(sph_ctx *ctx, int64_t count, const double *d_state);
 int sph_set_dt(sph_ctx *ctx, double dt, double t);
 int sph_get_dt(sph_ctx *ctx, double *dt, double *t);

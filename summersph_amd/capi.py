@@ -37,7 +37,7 @@ SYMBOLS = [
     "sph_download_field", "sph_download_field_dev", "sph_download_state",
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_refresh_eos_ghosts", "sph_dt_candidate", "sph_set_sink_accel",
-    "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_replace_ghosts_dev",
+    "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_select_boxes_async", "sph_selected_counts", "sph_gather_selected_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_pack_partials_dev", "sph_pack_partials_ex_dev",
     "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev", "sph_set_numbers_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
@@ -143,6 +143,9 @@ def load():
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.sph_pack_partials_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.sph_pack_partials_ex_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.sph_select_boxes_async.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.sph_selected_counts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.sph_gather_selected_dev.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     lib.sph_apply_partials_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.sph_set_boundary_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.sph_forces_part.argtypes = [C.c_void_p, C.c_int32]
@@ -332,6 +335,22 @@ class Context:
         counts = np.zeros(boxes.shape[0], dtype=np.int64)
         self._ck(self.lib.sph_select_boxes(self._h, boxes.shape[0], boxes.ctypes.data, counts.ctypes.data))
         return counts
+
+    def select_boxes_async(self, boxes: np.ndarray):
+        """the same selection without waiting for its counts (read them with selected_counts after a synchronisation)"""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        self._ck(self.lib.sph_select_boxes_async(self._h, boxes.shape[0], boxes.ctypes.data))
+        return boxes.shape[0]
+
+    def selected_counts(self, nbox: int) -> np.ndarray:
+        counts = np.zeros(nbox, dtype=np.int64)
+        self._ck(self.lib.sph_selected_counts(self._h, int(nbox), counts.ctypes.data))
+        return counts
+
+    def gather_selected_dev(self, box: int, names, capacity: int, out_ptr: int):
+        """out[0] = count, out[1] = 0, out[2 + f*count + k] (if count <= capacity) for selection `box`; device pointer"""
+        f = (C.c_int32 * len(names))(*[FIELDS.index(n) for n in names])
+        self._ck(self.lib.sph_gather_selected_dev(self._h, int(box), len(names), f, int(capacity), C.c_void_p(int(out_ptr))))
 
     def selected_ids_dev(self, box: int, count: int, dev_ptr: int):
         self._ck(self.lib.sph_selected_ids_dev(self._h, box, count, C.c_void_p(dev_ptr)))

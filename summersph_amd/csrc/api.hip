@@ -880,6 +880,35 @@ int sph_select_boxes(sph_ctx *c, int32_t nbox, const double *boxes, int64_t *cou
     return SPH_OK;
 }
 
+int sph_select_boxes_async(sph_ctx *c, int32_t nbox, const double *boxes) {
+    if (!c || nbox < 0 || nbox > MAX_SEL_BOXES || (nbox > 0 && !boxes)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    c->sel_boxes = 0;
+    API_TRY(domain_select_boxes_enqueue(c, nbox, boxes));
+    c->sel_boxes = nbox;
+    for (int b = 0; b < nbox; b++) c->sel_counts[b] = -1;          // unknown until sph_selected_counts
+    return SPH_OK;
+}
+
+int sph_selected_counts(sph_ctx *c, int32_t nbox, int64_t *counts) {
+    if (!c || nbox != c->sel_boxes || (nbox > 0 && !counts)) return SPH_ERR_ARG;
+    domain_selected_counts(c, nbox, counts);
+    for (int b = 0; b < nbox; b++) c->sel_counts[b] = counts[b];
+    return SPH_OK;
+}
+
+int sph_gather_selected_dev(sph_ctx *c, int32_t box, int32_t nf, const int32_t *fields, int64_t capacity, double *d_out) {
+    if (!c || box < 0 || box >= c->sel_boxes || capacity < 0 || !d_out) return SPH_ERR_ARG;
+    if (!fields_ok(c, nf, fields, true)) { c->err = "sph_gather_selected_dev: bad or stale field"; return SPH_ERR_ARG; }
+    DeviceGuard g(c->device);
+    if (c->n_owned == 0) {            // nothing selected, no id list: the header alone
+        API_HIP(hipMemsetAsync(d_out, 0, 2 * sizeof(double), c->stream));
+        return SPH_OK;
+    }
+    API_HIP(launch_gather_selected(c, nf, fields, box, capacity, d_out));
+    return SPH_OK;
+}
+
 int sph_selected_ids_dev(sph_ctx *c, int32_t box, int64_t count, int64_t *d_ids) {
     if (!c || box < 0 || box >= c->sel_boxes || count != c->sel_counts[box] || (count > 0 && !d_ids)) return SPH_ERR_ARG;
     if (count == 0) return SPH_OK;

@@ -143,21 +143,24 @@ __global__ void apply_partials(const double *__restrict__ all, int nranks, int s
         }                                                                   \
     } while (0)
 
-// ids (ascending original id) of the owned particles inside each of nbox boxes -> c->sel_ids + b * n_owned
-int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts) {
+// ids (ascending original id) of the owned particles inside each of nbox boxes -> c->sel_ids + b * n_owned; the counts stay
+// on the device (c->sel_count) and travel to pinned memory behind the selection, without a wait
+int domain_select_boxes_enqueue(sph_ctx *c, int nbox, const double *boxes) {
     const int64_t no = c->n_owned;
     c->sel_stride = no;
-    for (int b = 0; b < nbox; b++) counts[b] = 0;
-    if (no == 0 || nbox == 0) return SPH_OK;
+    int64_t *h = reinterpret_cast<int64_t *>(c->h_pinned + 64);
+    for (int b = 0; b < nbox; b++) h[b] = 0;
+    if (!c->sel_count) {
+        if (ctx_alloc(c, &c->sel_count, (size_t)MAX_SEL_BOXES, "selection counts") != SPH_OK) return SPH_ERR_NOMEM;
+    }
+    if (nbox == 0) return SPH_OK;
+    if (no == 0) { DM_CHECK(hipMemsetAsync(c->sel_count, 0, (size_t)nbox * sizeof(int64_t), c->stream)); return SPH_OK; }
     const size_t need = (size_t)nbox * (size_t)no;
     if (need > c->sel_cap) {
         ctx_free(c, c->sel_ids);
         c->sel_cap = 0;
         if (ctx_alloc(c, &c->sel_ids, need, "selection ids") != SPH_OK) return SPH_ERR_NOMEM;
         c->sel_cap = need;
-    }
-    if (!c->sel_count) {
-        if (ctx_alloc(c, &c->sel_count, (size_t)MAX_SEL_BOXES, "selection counts") != SPH_OK) return SPH_ERR_NOMEM;
     }
     rocprim::counting_iterator<int64_t> first(0);
     for (int b = 0; b < nbox; b++) {
@@ -175,10 +178,20 @@ int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *coun
         tmp = c->sel_tmp_bytes;
         DM_CHECK(rocprim::select(c->sel_tmp, tmp, first, c->sel_ids + (size_t)b * no, c->sel_count + b, (size_t)no, pred, c->stream));
     }
-    int64_t *h = reinterpret_cast<int64_t *>(c->h_pinned + 64);
     DM_CHECK(hipMemcpyAsync(h, c->sel_count, (size_t)nbox * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    DM_CHECK(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+void domain_selected_counts(sph_ctx *c, int nbox, int64_t *counts) {
+    const int64_t *h = reinterpret_cast<const int64_t *>(c->h_pinned + 64);
     for (int b = 0; b < nbox; b++) counts[b] = h[b];
+}
+
+int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts) {
+    const int st = domain_select_boxes_enqueue(c, nbox, boxes);
+    if (st != SPH_OK) return st;
+    DM_CHECK(hipStreamSynchronize(c->stream));
+    domain_selected_counts(c, nbox, counts);
     return SPH_OK;
 }
 

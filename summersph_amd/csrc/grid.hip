@@ -300,6 +300,18 @@ __global__ __launch_bounds__(256) void gather_by_id(FieldPtrs fp, const int32_t 
     for (int f = 0; f < fp.nf; f++) out[(size_t)f * count + k] = fp.p[f][slot];
 }
 
+// the same for a selection whose size only the device knows (sph_select_boxes_async): out[0] = count, out[1] = 0, then
+// out[2 + f * count + k] for k < count -- if count <= capacity; else the header alone (the caller asks again, exactly)
+__global__ __launch_bounds__(256) void gather_selected(FieldPtrs fp, const int32_t *__restrict__ inv, const int64_t *__restrict__ ids,
+                                                       const int64_t *__restrict__ count_ptr, int64_t capacity, double *__restrict__ out) {
+    const int64_t count = *count_ptr;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) { out[0] = (double)count; out[1] = 0.0; }
+    if (k >= count || count > capacity) return;
+    const int32_t slot = inv[ids[k]];
+    for (int f = 0; f < fp.nf; f++) out[2 + (size_t)f * count + k] = fp.p[f][slot];
+}
+
 // field_f[slot of original id first+k] = vals[f][k]
 __global__ __launch_bounds__(256) void scatter_many_by_id(FieldPtrs fp, const int32_t *__restrict__ inv, int64_t first,
                                                           int64_t count, const double *__restrict__ vals) {
@@ -317,6 +329,16 @@ hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int
     fp.nf = nf;
     for (int f = 0; f < nf; f++) fp.p[f] = c->f[fields[f]];
     gather_by_id<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->inv, ids, count, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_selected(sph_ctx *c, int nf, const int *fields, int box, int64_t capacity, double *out) {
+    FieldPtrs fp{};
+    fp.nf = nf;
+    for (int f = 0; f < nf; f++) fp.p[f] = c->f[fields[f]];
+    const int64_t threads = std::max<int64_t>(capacity, 1);
+    gather_selected<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream>>>(fp, c->inv, c->sel_ids + (size_t)box * c->sel_stride,
+                                                                                        c->sel_count + box, capacity, out);
     return hipGetLastError();
 }
 

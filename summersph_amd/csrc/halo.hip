@@ -496,18 +496,16 @@ int exchange_ghosts(sph_halo *h) {
         for (int a = 0; a < 3; a++) { sel[npeers * 6 + a] = b[a] - r; sel[npeers * 6 + 3 + a] = b[3 + a] + r; }
         peers[npeers++] = q;
     }
+    // The selection does not wait for its counts (sph_select_boxes_async): the payload is packed for the agreed room by a
+    // kernel that reads the count on the device, and the host learns both its own counts and the peers' at the one wait below.
     int64_t counts[MAXP], selc[MAXP];
     for (int q = 0; q < P; q++) counts[q] = 0;
-    if (npeers > 0) {
-        H_TRY(sph_select_boxes(h->c, npeers, sel, selc));
-        h->st.host_waits++;
-        for (int b = 0; b < npeers; b++) counts[peers[b]] = selc[b];
-    }
+    if (npeers > 0) H_TRY(sph_select_boxes_async(h->c, npeers, sel));
     // The payload travels without a size exchange: both sides of a pair agree on the room the message has (cap_send here =
     // cap_recv there, derived from the count of the last message between the two, 0 at first), the first two doubles say
     // how many particles there are.  Round A: header + rows in that room.  Round B, for the pairs whose count did not fit
     // (a first contact, a jump): the rows again at their exact size -- both sides know, the sender from its count, the
-    // receiver from the header.  Steady state: one round and one read-back of the headers, no collective.
+    // receiver from the header.  Steady state: one round and one read-back (headers + own counts), no collective.
     bool touching[MAXP];
     for (int q = 0; q < P; q++) touching[q] = false;
     for (int b = 0; b < npeers; b++) touching[peers[b]] = true;
@@ -517,17 +515,9 @@ int exchange_ghosts(sph_halo *h) {
     for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
-        const int64_t cnt = counts[q];
-        h->send_count[q] = cnt;
-        H_HIP(h->ids[q].need((size_t)std::max<int64_t>(cnt, 1) * 8));
-        H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * std::max(cnt, h->cap_send[q])) * 8));
+        H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * std::max<int64_t>(h->cap_send[q], 1)) * 8));
         H_HIP(h->recvb[q].need((size_t)(2 + NF * h->cap_recv[q]) * 8));
-        h->pin_hdr[2 * q] = (double)cnt; h->pin_hdr[2 * q + 1] = 0.0;
-        H_HIP(hipMemcpyAsync(h->sendb[q].p, h->pin_hdr + 2 * q, 16, hipMemcpyHostToDevice, h->s0));
-        if (cnt > 0) {
-            H_TRY(sph_selected_ids_dev(h->c, b, cnt, h->ids[q].as<int64_t>()));
-            H_TRY(sph_gather_fields_dev(h->c, NF, STATE, cnt, h->ids[q].as<int64_t>(), h->sendb[q].as<double>() + 2));
-        }
+        H_TRY(sph_gather_selected_dev(h->c, b, NF, STATE, h->cap_send[q], h->sendb[q].as<double>()));
         sp[q] = h->sendb[q].p; sb[q] = (size_t)(2 + NF * h->cap_send[q]) * 8;
         rp[q] = h->recvb[q].p; rb[q] = (size_t)(2 + NF * h->cap_recv[q]) * 8;
     }
@@ -537,21 +527,40 @@ int exchange_ghosts(sph_halo *h) {
     for (int b = 0; b < npeers; b++)
         H_HIP(hipMemcpyAsync(hdr_in + peers[b], h->recvb[peers[b]].p, 8, hipMemcpyDeviceToHost, h->s1));
     if (npeers > 0) if (int st = host_wait(h, h->s1)) return st;
+    if (npeers > 0) {
+        H_TRY(sph_selected_counts(h->c, npeers, selc));        // they arrived before the headers (same wait)
+        for (int b = 0; b < npeers; b++) counts[peers[b]] = selc[b];
+    }
     int64_t rc[MAXP], total = 0, roff[MAXP];
     for (int q = 0; q < P; q++) { rc[q] = touching[q] ? (int64_t)hdr_in[q] : 0; roff[q] = 2; total += rc[q]; }
-    // round B (every rank calls it, an empty group costs nothing): the pairs that did not fit
-    for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
+    // the id lists of what the peers now hold as ghosts (the field refreshes of this evaluation gather by them)
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
-        if (counts[q] > h->cap_send[q]) { sp[q] = h->sendb[q].as<double>() + 2; sb[q] = (size_t)NF * counts[q] * 8; }
+        h->send_count[q] = counts[q];
+        if (counts[q] == 0) continue;
+        H_HIP(h->ids[q].need((size_t)counts[q] * 8));
+        H_TRY(sph_selected_ids_dev(h->c, b, counts[q], h->ids[q].as<int64_t>()));
+    }
+    // round B (every rank calls it, an empty group costs nothing): the pairs that did not fit
+    for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
+    bool resend = false;
+    for (int b = 0; b < npeers; b++) {
+        const int q = peers[b];
+        if (counts[q] > h->cap_send[q]) {
+            H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * counts[q]) * 8));      // (re-allocation waits for the device: round A is complete)
+            H_TRY(sph_gather_fields_dev(h->c, NF, STATE, counts[q], h->ids[q].as<int64_t>(), h->sendb[q].as<double>() + 2));
+            sp[q] = h->sendb[q].as<double>() + 2; sb[q] = (size_t)NF * counts[q] * 8;
+            resend = true;
+        }
         if (rc[q] > h->cap_recv[q]) {
-            H_HIP(h->recvb[q].need((size_t)NF * rc[q] * 8));         // (re-allocation waits for the device: round A is complete)
+            H_HIP(h->recvb[q].need((size_t)NF * rc[q] * 8));
             rp[q] = h->recvb[q].p; rb[q] = (size_t)NF * rc[q] * 8;
             roff[q] = 0;
         }
         h->cap_send[q] = ghost_capacity(counts[q]);
         h->cap_recv[q] = ghost_capacity(rc[q]);
     }
+    if (resend) if (int st = s0_then_s1(h)) return st;
     if (int st = p2p_raw(h, sp, sb, rp, rb)) return st;
     if (int st = s1_then_s0(h)) return st;
     // every ghost lies inside its owner's box: particles farther than 2h from all of them cannot have a ghost neighbour

@@ -232,6 +232,7 @@ hipError_t launch_iota(sph_ctx *c, int32_t *p, int64_t n);
 hipError_t launch_fill(sph_ctx *c, double *p, double v, int64_t n);
 hipError_t launch_scatter_field(sph_ctx *c, double *field, int64_t first, int64_t count, const double *vals);
 hipError_t launch_gather_fields(sph_ctx *c, int nf, const int *fields, const int64_t *ids, int64_t count, double *out);
+hipError_t launch_gather_selected(sph_ctx *c, int nf, const int *fields, int box, int64_t capacity, double *out);
 hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t first, int64_t count, const double *vals);
 hipError_t launch_dt_partial_only(sph_ctx *c);
 hipError_t launch_kick_drift(sph_ctx *c);
@@ -240,6 +241,8 @@ hipError_t launch_kick_dt_candidate(sph_ctx *c);
 // multi-GPU building blocks (domain.hip, grid.hip)
 int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6);      // h_out6 != nullptr: synchronises
 int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts);
+int domain_select_boxes_enqueue(sph_ctx *c, int nbox, const double *boxes);     // the same without waiting: counts to pinned memory
+void domain_selected_counts(sph_ctx *c, int nbox, int64_t *counts);                // ... read after the caller's own synchronisation
 int domain_replace_ghosts(sph_ctx *c, int64_t count, const double *d_vals);
 hipError_t launch_pack_partials(sph_ctx *c, double *d_out, bool predict_box);
 hipError_t launch_set_numbers(sph_ctx *c, int64_t first, int64_t count, const int64_t *d_numbers);

@@ -161,6 +161,48 @@ def test_rank_reduction_and_device_dt(capi, torch):
     ctx.close()
 
 
+def test_selection_without_a_wait(capi, torch):
+    """sph_select_boxes_async + sph_gather_selected_dev + sph_selected_counts (the ghost exchange of csrc/halo.hip) against the
+    waiting forms: same counts, same ids, same packed rows; a selection that does not fit its room leaves the header alone"""
+    gas, sinks = _disc(20000, 11)
+    ctx = _upload(capi, torch, gas, np.arange(20000))
+    ctx.set_sinks(sinks)
+    ctx.density()
+    x = gas["x"]
+    boxes = np.array([[-1e9, -1e9, -1e9, np.quantile(x, 0.1), 1e9, 1e9],
+                      [np.quantile(x, 0.7), -1e9, -1e9, 1e9, 1e9, 1e9],
+                      [1e8, 1e8, 1e8, 2e8, 2e8, 2e8]])                     # the last one is empty
+    want = ctx.select_boxes(boxes)
+    ids_ref, rows_ref = [], []
+    names = ["x", "vy", "rho"]
+    for b, cnt in enumerate(want):
+        ids = torch.empty(int(cnt), dtype=torch.int64, device="cuda")
+        ctx.selected_ids_dev(b, int(cnt), ids.data_ptr())
+        out = torch.empty((3, int(cnt)), dtype=torch.float64, device="cuda")
+        if cnt:
+            ctx.gather_fields_dev(names, int(cnt), ids.data_ptr(), out.data_ptr())
+        ctx.synchronize()
+        ids_ref.append(ids.cpu().numpy()); rows_ref.append(out.cpu().numpy())
+    assert want[0] == np.count_nonzero(x <= boxes[0, 3]) and want[2] == 0
+    nb = ctx.select_boxes_async(boxes)
+    room = [int(want[0]) + 10, int(want[1]) - 1, 0]                       # fits, does not fit, empty
+    outs = [torch.full((2 + 3 * max(r, 1),), -7.0, dtype=torch.float64, device="cuda") for r in room]
+    for b in range(nb):
+        ctx.gather_selected_dev(b, names, room[b], outs[b].data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(ctx.selected_counts(nb), want)
+    got = [o.cpu().numpy() for o in outs]
+    assert got[0][0] == want[0] and got[0][1] == 0.0
+    assert np.array_equal(got[0][2:2 + 3 * want[0]].reshape(3, -1), rows_ref[0])
+    assert got[1][0] == want[1] and np.all(got[1][2:] == -7.0)           # header alone
+    assert got[2][0] == 0.0
+    ids = torch.empty(int(want[1]), dtype=torch.int64, device="cuda")
+    ctx.selected_ids_dev(1, int(want[1]), ids.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), ids_ref[1])
+    ctx.close()
+
+
 def test_fused_kick_calls_are_bitwise_the_separate_ones(capi, torch):
     """sph_kick_drift_devdt == sph_kick_devdt + sph_drift_devdt; sph_kick_dt_candidate_dev == sph_kick_devdt +
     sph_dt_candidate_dev (state, sink velocities and the candidate).  All particles owned: ghost rho / rates are whatever
