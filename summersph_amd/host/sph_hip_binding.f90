@@ -20,6 +20,7 @@ module sph_hip_binding
   public :: SPH_FLAG_SINK_CREATION, sph_sink_count, sph_get_sink_radii
   ! multi-GPU building blocks (device pointers as type(c_ptr), e.g. from hipMalloc or an MPI library's GPU buffers)
   public :: sph_set_owned, sph_set_rank, sph_reserve, sph_owned_bbox, sph_select_boxes, sph_selected_ids_dev
+  public :: sph_select_boxes_async, sph_selected_counts, sph_gather_selected_dev
   public :: sph_replace_ghosts_dev, sph_gather_fields_dev, sph_scatter_fields_dev, sph_refresh_eos_ghosts
   public :: sph_set_boundary_boxes, sph_forces_part, sph_set_dt, sph_get_dt, sph_kick_devdt, sph_drift_devdt
   public :: sph_kick_drift_devdt, sph_kick_dt_candidate_dev
@@ -287,6 +288,25 @@ module sph_hip_binding
       type(c_ptr), value :: ctx, d_ids
       integer(c_int32_t), value :: box
       integer(c_int64_t), value :: count
+    end function
+    integer(c_int) function sph_select_boxes_async(ctx, nbox, boxes) bind(C, name='sph_select_boxes_async')
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nbox
+      real(c_double), intent(in) :: boxes(*)
+    end function
+    integer(c_int) function sph_selected_counts(ctx, nbox, counts) bind(C, name='sph_selected_counts')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nbox
+      integer(c_int64_t), intent(out) :: counts(*)
+    end function
+    integer(c_int) function sph_gather_selected_dev(ctx, box, nf, fields, capacity, d_out) bind(C, name='sph_gather_selected_dev')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: ctx, d_out
+      integer(c_int32_t), value :: box, nf
+      integer(c_int32_t), intent(in) :: fields(*)
+      integer(c_int64_t), value :: capacity
     end function
     integer(c_int) function sph_replace_ghosts_dev(ctx, count, d_state) bind(C, name='sph_replace_ghosts_dev')
       import :: c_int, c_int64_t, c_ptr
