@@ -240,6 +240,46 @@ def test_four_ranks_many_migrations_and_a_second_upload():
     assert out[0][1]["stats"].migrations >= 14 and out[0][1]["stats"].migrated > 0
 
 
+def test_a_rank_that_owns_nothing():
+    """three ranks, the third slab lies beyond the disc: the empty rank takes part in every collective and message round"""
+    rows = ic.keplerian_disc(9000, seed=45)
+    gas, sinks = ic.split_rows(rows)
+    world = 3
+    hub = halo.Hub(world)
+    bounds = np.array([0.0, gas["x"].max() + 100.0])
+    owner = np.searchsorted(bounds, gas["x"], side="right")
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = capi.Context(device=0)
+            h = halo.Halo.inproc(ctx, hub, rank, world)
+            sel = owner == rank
+            mine = {k: v[sel] for k, v in gas.items()}
+            mine["gid"] = np.nonzero(sel)[0]
+            ctx.set_sinks(sinks); h.set_slabs(bounds, 2); h.upload(mine)
+            dt, t = h.run(6, 1e-2, 0.0)
+            out[rank] = (dt, h.download(), h.stats().ghosts)
+            h.close(); ctx.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    hub.close()
+    assert not errs, errs
+    assert out[2][1]["x"].size == 0 and out[2][2] == 0 and out[0][2] > 0
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = ctx.run(6, 1e-2, 0.0)
+    order = np.argsort(np.concatenate([o[1]["gid"] for o in out]))
+    assert all(o[0] == dt for o in out)
+    for f in FIELDS:
+        assert rel_err(np.concatenate([o[1][f] for o in out])[order], ctx.field(f)) <= 1e-11, f
+    ctx.close()
+
+
 def test_fortran_multi_gpu_host_one_rank(tmp_path):
     """run_sph_hip_mg with one rank (RCCL communicator of size 1, id through the file) writes what run_sph_hip ... sph
     writes: same dt decisions, same snapshot, byte for byte"""
