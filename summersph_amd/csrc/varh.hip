@@ -462,6 +462,8 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_reflag(const double4 *__restri
         ReflagStage st;
         st.j = 0; st.cls = 0; st.d = false; st.rji = false; st.lj = li; st.oj = 0;
         int4 outp = make_int4(0, 0, 0, 0);                  // the previous row, waiting for its fourth entry
+        int4 qprev = make_int4(0, 0, 0, 0);                 // ... as it stands in memory: most rows come out unchanged and are not written
+        auto same = [](const int4 &a, const int4 &b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0; };
         for (int r = 0; r < nrow; r++) {
             const int4 qc = load_row(mine + (size_t)min(r + 2, nrow - 1) * 64);
             int4 out = make_int4(0, 0, 0, 0);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_reflag(const double4 *__restri
                 if (v == 0) {
                     if (r > 0) {
                         outp.w = reflag_finish(pi, oi, st, number);
-                        if (4 * (r - 1) < cnt_a) mine[(size_t)(r - 1) * 64] = outp;
+                        if (4 * (r - 1) < cnt_a && !same(outp, qprev)) mine[(size_t)(r - 1) * 64] = outp;
                         if (r - 1 == (cnt_a >> 2)) last = outp;
                     }
                 } else {
@@ -488,11 +490,11 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_reflag(const double4 *__restri
                 }
                 reflag_classify(pi, li, ri2, k < cnt_a, e0 & IDX_MASK, pj, lrec, orig, st);
             }
-            outp = out;
+            outp = out; qprev = qa;
             qa = qb; qb = qc;
         }
         outp.w = reflag_finish(pi, oi, st, number);
-        if (4 * (nrow - 1) < cnt_a) mine[(size_t)(nrow - 1) * 64] = outp;
+        if (4 * (nrow - 1) < cnt_a && !same(outp, qprev)) mine[(size_t)(nrow - 1) * 64] = outp;
         if (nrow - 1 == (cnt_a >> 2)) last = outp;
     }
     // pass 2: the margin shell, rows in ascending row index (= descending entry number); what the new lengths switch on is
