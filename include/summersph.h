@@ -267,6 +267,8 @@ int sph_scatter_fields_dev(sph_ctx *ctx, int32_t nf, const int32_t *fields, int6
  *                     (sph_run's mechanism), so that a step needs no host round trip for them.
  * sph_kick_drift_devdt / sph_kick_dt_candidate_dev: the same pairs of calls fused into one pass over the state each
  *                     (kick + drift; closing kick + local dt candidate), bitwise the separate calls.
+ *                     sph_kick_dt_candidate_gas_dev + sph_kick_sinks_devdt split the latter into its gas and its sink part, so
+ *                     that the gas is kicked while the sinks' accelerations still travel through the rank reduction.
  * sph_dt_candidate_dev    local dt candidate ([F]:845-851 over owned particles) kept on the device.
  * sph_pack_partials_dev   d_out[0..3*64) = this GPU's partial sink accelerations (ax[64] ay[64]
  *                     az[64]), d_out[192] = its dt candidate, d_out[193..199) = the bounding box its owned particles
@@ -326,6 +328,8 @@ int sph_drift_devdt(sph_ctx *ctx);
 int sph_dt_candidate_dev(sph_ctx *ctx);
 int sph_kick_drift_devdt(sph_ctx *ctx);
 int sph_kick_dt_candidate_dev(sph_ctx *ctx);
+int sph_kick_dt_candidate_gas_dev(sph_ctx *ctx);
+int sph_kick_sinks_devdt(sph_ctx *ctx);
 int sph_pack_partials_dev(sph_ctx *ctx, double *d_out);
 int sph_pack_partials_ex_dev(sph_ctx *ctx, double *d_out, int32_t predict_box);
 int sph_apply_partials_dev(sph_ctx *ctx, const double *d_all, int32_t nranks, int32_t stride, int32_t apply_dt);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "sph_gather_fields_dev", "sph_scatter_fields_dev",
     "sph_set_owned", "sph_set_rank", "sph_scatter_field_dev", "sph_refresh_eos", "sph_refresh_eos_ghosts", "sph_dt_candidate", "sph_set_sink_accel",
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_select_boxes_async", "sph_selected_counts", "sph_gather_selected_dev", "sph_replace_ghosts_dev",
-    "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_pack_partials_dev", "sph_pack_partials_ex_dev",
+    "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_kick_dt_candidate_gas_dev", "sph_kick_sinks_devdt", "sph_pack_partials_dev", "sph_pack_partials_ex_dev",
     "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev", "sph_set_numbers_dev",
     "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
@@ -139,7 +139,8 @@ def load():
     lib.sph_replace_ghosts_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     lib.sph_set_dt.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.sph_get_dt.argtypes = [C.c_void_p, _D, _D]
-    for f in ("sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev"):
+    for f in ("sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev",
+              "sph_kick_dt_candidate_gas_dev", "sph_kick_sinks_devdt"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.sph_pack_partials_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.sph_pack_partials_ex_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -380,6 +381,12 @@ class Context:
 
     def kick_dt_candidate_dev(self):
         self._ck(self.lib.sph_kick_dt_candidate_dev(self._h))
+
+    def kick_dt_candidate_gas_dev(self):
+        self._ck(self.lib.sph_kick_dt_candidate_gas_dev(self._h))
+
+    def kick_sinks_devdt(self):
+        self._ck(self.lib.sph_kick_sinks_devdt(self._h))
 
     def pack_partials_dev(self, dev_ptr: int, predict_box: bool = True):
         self._ck(self.lib.sph_pack_partials_ex_dev(self._h, C.c_void_p(dev_ptr), 1 if predict_box else 0))

@@ -1035,6 +1035,25 @@ int sph_kick_dt_candidate_dev(sph_ctx *c) {
     return SPH_OK;
 }
 
+// the same for the gas alone, and the sinks' half kick by itself: between the two the sinks' accelerations may still be on
+// their way through the rank reduction (bitwise sph_kick_dt_candidate_dev when called back to back)
+int sph_kick_dt_candidate_gas_dev(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    if (!c->rates_valid) { c->err = "sph_kick_dt_candidate_gas_dev: rates are stale, call sph_forces first"; return SPH_ERR_STATE; }
+    DeviceGuard g(c->device);
+    Timed t(c, SPH_K_DT);
+    API_HIP(launch_kick_dt_candidate(c, false));
+    c->eos_valid = false;
+    return SPH_OK;
+}
+
+int sph_kick_sinks_devdt(sph_ctx *c) {
+    if (!c) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    API_HIP(launch_kick_sinks(c));
+    return SPH_OK;
+}
+
 int sph_dt_candidate_dev(sph_ctx *c) {
     if (!c) return SPH_ERR_ARG;
     if (!c->rates_valid) { c->err = "sph_dt_candidate_dev: rates are stale"; return SPH_ERR_STATE; }

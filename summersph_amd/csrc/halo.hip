@@ -619,21 +619,29 @@ int refresh_finish(sph_halo *h) {
 
 // sink accelerations summed over ranks; a pending dt candidate min-reduced and the dt rule applied; the same message
 // carries every rank's predicted box after the coming kick + drift (dist.py _reduce)
-int reduce(sph_halo *h, bool before_drift) {
+// In two halves, so that the caller can put work between them that does not need the sums: reduce_start packs and sends the
+// partials off (all-gather on s1), reduce_finish lets s0 wait for them and applies them.
+int reduce_start(sph_halo *h, bool before_drift) {
     H_HIP(h->part.need(SPH_PARTIALS * 8));
     // the predicted box costs a pass over the particles: only where a drift follows and other ranks read it
     H_TRY(sph_pack_partials_ex_dev(h->c, h->part.as<double>(), (before_drift && h->P > 1) ? 1 : 0));
-    if (h->P == 1) {
-        H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, h->dt_pending ? 1 : 0));
-        h->pred_valid = false;
-    } else {
+    if (h->P > 1) {
         H_HIP(h->allpart.need((size_t)h->P * SPH_PARTIALS * 8));
         if (int st = s0_then_s1(h)) return st;
         H_TR(h->tr->allgather(h->part.p, h->allpart.p, SPH_PARTIALS * 8, h->s1));
         h->st.collectives++;
         // to the host without stalling either stream: read after the drift
-        H_HIP(hipMemcpyAsync(h->pin_part, h->allpart.p, (size_t)h->P * SPH_PARTIALS * 8, hipMemcpyDeviceToHost, h->s1));
+        if (before_drift) H_HIP(hipMemcpyAsync(h->pin_part, h->allpart.p, (size_t)h->P * SPH_PARTIALS * 8, hipMemcpyDeviceToHost, h->s1));
         H_HIP(hipEventRecord(h->e_pred, h->s1));
+    }
+    return SPH_OK;
+}
+
+int reduce_finish(sph_halo *h, bool before_drift) {
+    if (h->P == 1) {
+        H_TRY(sph_apply_partials_dev(h->c, h->part.as<double>(), 1, SPH_PARTIALS, h->dt_pending ? 1 : 0));
+        h->pred_valid = false;
+    } else {
         H_HIP(hipStreamWaitEvent(h->s0, h->e_pred, 0));
         H_TRY(sph_apply_partials_dev(h->c, h->allpart.as<double>(), h->P, SPH_PARTIALS, h->dt_pending ? 1 : 0));
         h->pred_valid = before_drift;
@@ -671,17 +679,22 @@ int evaluate(sph_halo *h, bool before_drift) {
     } else {
         H_TRY(sph_forces(h->c));
     }
-    return reduce(h, before_drift);
+    return reduce_start(h, before_drift);
 }
 
 int step(sph_halo *h) {
     if (int st = evaluate(h, true)) return st;
+    if (int st = reduce_finish(h, true)) return st;       // the kick needs the new dt: nothing to put in between
     H_TRY(sph_kick_drift_devdt(h->c));
     h->pos_dirty = true;
     h->pred_for_drift = true;                   // the reduction above predicted where this drift takes everybody
     h->since_migrate++;
     if (int st = evaluate(h, false)) return st;           // a kick follows, no drift
-    H_TRY(sph_kick_dt_candidate_dev(h->c));      // closing kick + get_next_timestep's local part, [F]:845-851; reduced with the next evaluation
+    // closing kick + get_next_timestep's local part ([F]:845-851; reduced with the next evaluation) for the gas while the sinks'
+    // accelerations travel; the sinks are kicked when they have arrived
+    H_TRY(sph_kick_dt_candidate_gas_dev(h->c));
+    if (int st = reduce_finish(h, false)) return st;
+    H_TRY(sph_kick_sinks_devdt(h->c));
     h->vel_dirty = true;
     h->dt_pending = true;
     return SPH_OK;

@@ -231,14 +231,29 @@ hipError_t launch_kick_next_dt(sph_ctx *c, bool advance_t) {
     return hipGetLastError();
 }
 
-// multi-GPU: the closing kick + the LOCAL dt candidate in one pass (kick_dt_kernel), the rule itself after the rank reduction
-hipError_t launch_kick_dt_candidate(sph_ctx *c) {
+// the sinks' half kick alone ([F]:753-755), for a gas kick launched with ns = 0
+__global__ void sink_kick_kernel(const double *__restrict__ dt_ptr, double *__restrict__ sink, int ns) {
+    const int s = threadIdx.x;
+    if (s >= ns) return;
+    const double dt = dt_ptr[0];
+    for (int k = 0; k < 3; k++)
+        sink[(3 + k) * MAX_SINKS + s] = sink[(3 + k) * MAX_SINKS + s] + 0.5 * sink[(7 + k) * MAX_SINKS + s] * dt;
+}
+
+hipError_t launch_kick_sinks(sph_ctx *c) {
+    if (c->ns > 0) sink_kick_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_dt, c->sink, c->ns);
+    return hipGetLastError();
+}
+
+// multi-GPU: the closing kick + the LOCAL dt candidate in one pass (kick_dt_kernel), the rule itself after the rank reduction;
+// with_sinks = false leaves the sinks' velocities alone (their accelerations may still be travelling between the ranks)
+hipError_t launch_kick_dt_candidate(sph_ctx *c, bool with_sinks) {
     KickArgs a{c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_U], c->f[SPH_F_ALPHA],
                c->f[SPH_F_AX], c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA]};
     int nb = (int)std::min<int64_t>((c->n + DT_BLOCK - 1) / DT_BLOCK, c->dt_blocks);
     if (nb < 1) nb = 1;
-    kick_dt_kernel<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(a, c->f[SPH_F_C], c->p.h, c->n, c->d_dt, c->sink, c->ns, c->dt_part, c->orig,
-                                                               (int32_t)c->n_owned, c->variable ? c->f[SPH_F_H] : nullptr);
+    kick_dt_kernel<<<dim3(nb), dim3(DT_BLOCK), 0, c->stream>>>(a, c->f[SPH_F_C], c->p.h, c->n, c->d_dt, c->sink, with_sinks ? c->ns : 0, c->dt_part,
+                                                               c->orig, (int32_t)c->n_owned, c->variable ? c->f[SPH_F_H] : nullptr);
     dt_candidate_only<<<dim3(1), dim3(64), 0, c->stream>>>(c->dt_part, nb, c->p.dt_scale, c->d_dt);
     return hipGetLastError();
 }

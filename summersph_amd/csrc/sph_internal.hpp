@@ -237,7 +237,8 @@ hipError_t launch_scatter_fields(sph_ctx *c, int nf, const int *fields, int64_t 
 hipError_t launch_dt_partial_only(sph_ctx *c);
 hipError_t launch_kick_drift(sph_ctx *c);
 hipError_t launch_kick_next_dt(sph_ctx *c, bool advance_t);   // closing kick + get_next_timestep in one pass      // kick + drift with the device dt in one pass (sph_step / sph_run)
-hipError_t launch_kick_dt_candidate(sph_ctx *c);
+hipError_t launch_kick_dt_candidate(sph_ctx *c, bool with_sinks = true);
+hipError_t launch_kick_sinks(sph_ctx *c);
 // multi-GPU building blocks (domain.hip, grid.hip)
 int owned_bbox(sph_ctx *c, double *d_out6, double *h_out6);      // h_out6 != nullptr: synchronises
 int domain_select_boxes(sph_ctx *c, int nbox, const double *boxes, int64_t *counts);

@@ -23,7 +23,7 @@ module sph_hip_binding
   public :: sph_select_boxes_async, sph_selected_counts, sph_gather_selected_dev
   public :: sph_replace_ghosts_dev, sph_gather_fields_dev, sph_scatter_fields_dev, sph_refresh_eos_ghosts
   public :: sph_set_boundary_boxes, sph_forces_part, sph_set_dt, sph_get_dt, sph_kick_devdt, sph_drift_devdt
-  public :: sph_kick_drift_devdt, sph_kick_dt_candidate_dev
+  public :: sph_kick_drift_devdt, sph_kick_dt_candidate_dev, sph_kick_dt_candidate_gas_dev, sph_kick_sinks_devdt
   public :: sph_dt_candidate_dev, sph_pack_partials_dev, sph_pack_partials_ex_dev, sph_apply_partials_dev, sph_set_gravity_sources_dev
   public :: SPH_PARTIALS
   public :: c_message
@@ -357,6 +357,16 @@ module sph_hip_binding
       type(c_ptr), value :: ctx
     end function
     integer(c_int) function sph_kick_drift_devdt(ctx) bind(C, name='sph_kick_drift_devdt')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function sph_kick_dt_candidate_gas_dev(ctx) bind(C, name='sph_kick_dt_candidate_gas_dev')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function sph_kick_sinks_devdt(ctx) bind(C, name='sph_kick_sinks_devdt')
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
     end function
