@@ -209,7 +209,7 @@ def test_fused_kick_calls_are_bitwise_the_separate_ones(capi, torch):
     their owners last sent, which this test does not stage (the ghost protocol is covered by test_halo_gpu / test_dist_gpu)"""
     gas, sinks = _disc(6000, 9)
     res = []
-    for fused in (False, True):
+    for fused in (False, True, "split"):
         ctx = _upload(capi, torch, gas, np.arange(6000))
         ctx.set_sinks(sinks)
         ctx.set_dt(0.013, 0.0)
@@ -219,7 +219,9 @@ def test_fused_kick_calls_are_bitwise_the_separate_ones(capi, torch):
         else:
             ctx.kick_devdt(); ctx.drift_devdt()
         ctx.density(); ctx.forces()
-        if fused:
+        if fused == "split":          # the gas and the sink half of the closing kick as two calls
+            ctx.kick_dt_candidate_gas_dev(); ctx.kick_sinks_devdt()
+        elif fused:
             ctx.kick_dt_candidate_dev()
         else:
             ctx.kick_devdt(); ctx.dt_candidate_dev()
@@ -234,6 +236,7 @@ def test_fused_kick_calls_are_bitwise_the_separate_ones(capi, torch):
         ctx.close()
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k
+        assert np.array_equal(res[0][k], res[2][k]), k
 
 
 def test_context_on_callers_stream(capi, torch):
