@@ -52,6 +52,7 @@ void free_particle_arrays(sph_ctx *c) {
     gravity_free(c);                                     // tree arrays are (re)allocated by the next tree build
     c->msort_tmp_bytes = 0;
     c->cap = 0; c->nl_cap = 0; c->nl_waves_cap = 0; c->sort_tmp_bytes = 0;
+    c->h_new_is_build = false; c->list_has_margin = false;
 }
 
 int ensure_capacity(sph_ctx *c, int64_t n) {
@@ -173,7 +174,10 @@ int do_density(sph_ctx *c) {
     if (!no_refresh && !c->grid_valid && c->variable && c->h_refresh_ok && c->order_valid && c->leaf_valid && c->n_slots == c->n) {
         // same positions, same particles, new h (calc_smoothing, Variable.f90:1152): the sorted order, the cell table and
         // the leaf cells stand; only what depends on h is redone -- and a self-gravity tree stays valid
-        API_TRY(varh_h_stats(c, true));
+        // growth of h against the lengths the list was built with -- known only when sph_update_h produced the new h (its
+        // swap left the old lengths in h_new); after an upload / scatter of h the list is built, never re-flagged
+        API_TRY(varh_h_stats(c, c->h_new_is_build));
+        c->h_new_is_build = false;
         { Timed t(c, SPH_K_LEAF); API_TRY(varh_refresh_h(c)); }
         {   // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built
             Timed t(c, SPH_K_NLIST);
@@ -185,6 +189,7 @@ int do_density(sph_ctx *c) {
     }
     c->h_refresh_ok = false;
     if (!c->grid_valid) {
+        c->h_new_is_build = false;
         if (c->variable) API_TRY(varh_h_stats(c));
         { Timed t(c, SPH_K_GRID); API_TRY(grid_rebuild(c)); }
         c->order_valid = true; c->derived_kept = false; c->grav_valid = false;
@@ -288,9 +293,30 @@ int put_dt(sph_ctx *c, double dt, double t) {
     return SPH_OK;
 }
 
+// The fixed-h build path reads its reports (longest list, non-finite positions) one build late so that the steady state never
+// waits for the host.  Every entry point that synchronises anyway and hands results to the caller calls this afterwards: the
+// reports of the LAST build have arrived by then, so a list that overflowed in the final build of a run (or in the only build
+// after an upload) is an error here, never a silently truncated result.  Requires the stream to be idle.
+int drain_reports(sph_ctx *c) {
+    if (c->ring_nl_valid) {
+        const int32_t *rep = reinterpret_cast<const int32_t *>(c->h_pinned + 240 + 8 * (1 - c->ring_nl));
+        if (rep[0] > c->nl_cap) {
+            c->err = "neighbour list overflowed in the last build (lists grew by more than a third within one step): results are incomplete";
+            c->ring_nl_valid = false; c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; c->rates_valid = false;
+            return SPH_ERR_STATE;
+        }
+    }
+    if (c->ring_bbox_valid && !c->bbox_exact) {
+        const double *bb = c->h_pinned + 200 + 16 * (1 - c->ring_bbox);
+        if (*reinterpret_cast<const int32_t *>(bb + 6) != 0) { c->err = "non-finite particle position at grid build"; return SPH_ERR_NONFINITE; }
+    }
+    return SPH_OK;
+}
+
 int get_dt(sph_ctx *c, double *dt, double *t) {
     API_HIP(hipMemcpyAsync(c->h_pinned + 20, c->d_dt, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     API_HIP(hipStreamSynchronize(c->stream));
+    API_TRY(drain_reports(c));
     if (dt) *dt = c->h_pinned[20];
     if (t) *t = c->h_pinned[21];
     return SPH_OK;
@@ -305,6 +331,7 @@ int do_update_h(sph_ctx *c) {
     // h changed: reaches, neighbour sets, rho all depend on it -- but nothing else does (do_density's short path)
     c->grid_valid = false; c->rho_valid = false; c->eos_valid = false;
     c->h_refresh_ok = true;
+    c->h_new_is_build = true;                           // launch_update_h swapped: h_new = the lengths of the list in place
     c->grav_valid = false;                              // the softening length of [V]:296 is the particle's own h
     return SPH_OK;
 }
@@ -357,6 +384,12 @@ void field_written(sph_ctx *c, int field) {
     if (field <= SPH_F_Z || field == SPH_F_M || field == SPH_F_H) {
         c->h_refresh_ok = field == SPH_F_H && (c->grid_valid || c->h_refresh_ok);     // only h is newer than the grid
         c->grid_valid = false; c->rho_valid = false;
+    }
+    if (field == SPH_F_H) c->h_new_is_build = false;     // h_new no longer pairs with the new h: the next list is built, not re-flagged
+    if (field <= SPH_F_Z || field == SPH_F_M) {
+        // a new configuration: the one-build-late reports (list overflow, bounding box, non-finite flag) describe the old one,
+        // so the next build waits for its own read-backs instead of trusting them
+        c->ring_nl_valid = false; c->ring_bbox_valid = false;
     }
     if (field <= SPH_F_Z) c->order_valid = false;
     if (field <= SPH_F_ALPHA || field == SPH_F_RHO || field == SPH_F_H || field == SPH_F_OMEGA) c->eos_valid = false;
@@ -582,6 +615,7 @@ static int upload_impl(sph_ctx *c, int64_t n, const double *const src[9], hipMem
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->order_valid = c->tree_valid = false;
     c->derived_kept = false;
     c->ring_bbox_valid = c->ring_nl_valid = false;       // a new particle set: the next build waits for its own read-backs
+    c->h_new_is_build = false; c->h_refresh_ok = false;
     return SPH_OK;
 }
 
@@ -657,7 +691,7 @@ int sph_download_field_dev(sph_ctx *c, int field, double *d_out, int64_t n) {
     DeviceGuard g(c->device);
     API_HIP(launch_unpermute(c, c->f[field], d_out));
     API_HIP(hipStreamSynchronize(c->stream));
-    return SPH_OK;
+    return drain_reports(c);
 }
 
 int sph_download_field(sph_ctx *c, int field, double *host, int64_t n) {
@@ -668,7 +702,7 @@ int sph_download_field(sph_ctx *c, int field, double *host, int64_t n) {
     API_HIP(launch_unpermute(c, c->f[field], c->scratch));
     API_HIP(hipMemcpyAsync(host, c->scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     API_HIP(hipStreamSynchronize(c->stream));
-    return SPH_OK;
+    return drain_reports(c);
 }
 
 int sph_download_state(sph_ctx *c, int64_t n, double *x, double *y, double *z, double *vx, double *vy, double *vz,
@@ -696,6 +730,7 @@ int sph_get_stats(sph_ctx *c, sph_stats *o) {
         DeviceGuard g(c->device);
         std::vector<int32_t> cnt((size_t)c->n);
         API_HIP(hipStreamSynchronize(c->stream));
+        API_TRY(drain_reports(c));
         API_HIP(hipMemcpy(cnt.data(), c->ncount, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         double s = 0.0, sw = 0.0;
         for (int32_t v : cnt) s += v;
@@ -1117,7 +1152,7 @@ int sph_synchronize(sph_ctx *c) {
     if (!c) return SPH_ERR_ARG;
     DeviceGuard g(c->device);
     API_HIP(hipStreamSynchronize(c->stream));
-    return SPH_OK;
+    return drain_reports(c);
 }
 
 void *sph_stream(sph_ctx *c) { return c ? (void *)c->stream : nullptr; }

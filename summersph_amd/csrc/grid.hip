@@ -133,8 +133,9 @@ __device__ __forceinline__ uint32_t cell_key(const GridDesc &g, double px, doubl
     int c[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        int v = (int)((p[a] - g.org[a]) * g.inv_edge);
-        c[a] = min(max(v, 0), g.dim[a] - 1);
+        // clamped as a double BEFORE the cast: a particle far outside the (stale or trimmed) box, or a NaN that is reported a
+        // build late, must not reach an out-of-range float -> int conversion (undefined in C++); fmax drops a NaN -> cell 0
+        c[a] = (int)fmin(fmax((p[a] - g.org[a]) * g.inv_edge, 0.0), (double)(g.dim[a] - 1));
     }
     cc[0] = c[g.s[0]]; cc[1] = c[g.s[1]]; cc[2] = c[g.s[2]];
     return ((uint32_t)cc[2] * (uint32_t)g.dim[g.s[1]] + (uint32_t)cc[1]) * (uint32_t)g.dim[g.s[0]] + (uint32_t)cc[0];

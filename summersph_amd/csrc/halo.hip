@@ -490,8 +490,15 @@ int exchange_ghosts(sph_halo *h) {
         h->send_count[q] = 0;
         if (q == h->rank || !mine_ok || !finite6(q)) continue;
         const double *b = &boxes[(size_t)q * 6];
+        // ONE expression, evaluated identically by both ranks of a pair (operands ordered by rank): each side posts a
+        // receive for the other's header, so a decision that differed by an ulp at gap == r would leave a send without
+        // its partner
+        const double *lo_rank = q < h->rank ? b : me, *hi_rank = q < h->rank ? me : b;
         bool touch = true;
-        for (int a = 0; a < 3; a++) if (me[3 + a] < b[a] - r || me[a] > b[3 + a] + r) touch = false;
+        for (int a = 0; a < 3; a++) {
+            const double gap = std::max(hi_rank[a] - lo_rank[3 + a], lo_rank[a] - hi_rank[3 + a]);
+            if (!(gap <= r)) touch = false;
+        }
         if (!touch) continue;
         for (int a = 0; a < 3; a++) { sel[npeers * 6 + a] = b[a] - r; sel[npeers * 6 + 3 + a] = b[3 + a] + r; }
         peers[npeers++] = q;

@@ -107,6 +107,8 @@ struct sph_ctx {
     double *leaf_half = nullptr;     // half edge of every slot's leaf cell (reach = 2 h + this)
     bool path_keys_valid = false;    // mkeys_alt / mvals_alt hold the sorted octree path keys of the current grid build (root box: c->bbox)
     bool h_refresh_ok = false;       // the only thing newer than the grid is h (sph_update_h / an upload of h)
+    bool h_new_is_build = false;     // h_new holds the lengths the list in place was built with (set by sph_update_h's swap; an
+                                     // upload / scatter of h, a new particle set or a reallocation clears it: no re-flag then)
     bool leaf_valid = false;         // leaf cells match the current sorted order and (external) octree
     double h_max_glob = 0.0, h_mean = 0.0;
     double root_box[4] = {0, 0, 0, 0};   // octree root centre + edge ([V]:1007-1012)

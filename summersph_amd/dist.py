@@ -439,7 +439,11 @@ class DistSim:
             if q == self.rank or not mine_ok or not np.all(np.isfinite(boxes[q])):
                 continue
             lo, hi = boxes[q, :3] - r, boxes[q, 3:] + r
-            if np.any(me_hi < lo) or np.any(me_lo > hi):          # boxes do not touch: nothing to send
+            # one expression both ranks of a pair evaluate identically (operands ordered by rank): each side posts a receive
+            # for the other's message, so the two decisions must never differ by an ulp at gap == r
+            a_, b_ = (boxes[q], boxes[self.rank]) if q < self.rank else (boxes[self.rank], boxes[q])
+            gap = np.maximum(b_[:3] - a_[3:], a_[:3] - b_[3:])
+            if not np.all(gap <= r):                              # boxes do not touch: nothing to send
                 continue
             peers.append(q)
             sel.append(np.concatenate([lo, hi]))

@@ -83,8 +83,11 @@ contains
       ! A record is a run of values that may continue over line breaks, as for the reference's list-directed read
       ! ([F]:647).  One record per line: the first eight values count, further columns are skipped.  A record wrapped
       ! over several lines (a save written with list-directed output under flang: 80 columns per line) carries
-      ! 9 values for a gas particle (..., alpha) and 8 for a sink: when the 8th value ends a line, a following line
-      ! that holds a single value is the wrapped alpha of this record, not the start of the next one.
+      ! 9 values for a gas particle (..., alpha) and 8 for a sink.  Framing rule, independent of the values read: every
+      ! record starts on a new line and a wrapped record's first line holds as many values as fit (at least two at 80
+      ! columns), so when the 8th value ends a line, a following line that holds a SINGLE value is the 9th value of
+      ! this record and never the start of the next one.  A file with one value per line cannot be framed that way and
+      ! is rejected instead of being guessed at.
       call next_values(unit_no, line, pos, v, nread, nlines, ios)
       if (nread == 0) exit                         ! end of file between records
       if (ios /= 0) then
@@ -92,10 +95,16 @@ contains
         exit
       end if
       wrapped = nlines + buffered >= 2
+      if (nlines + buffered >= 8) then
+        write(*, *) 'Error: ', trim(filename), ' holds one value per line near record ', nrec + 1, &
+                    ': records cannot be framed (8 or 9 values?); write one record per line'
+        nrec = 0
+        exit
+      end if
       at_line_end = tokens_left(line, pos) == 0
       pos = len(line) + 1                          ! what is left of the line belongs to this record
       buffered = 0
-      if (wrapped .and. at_line_end .and. v(7) /= 0.0_dp) then
+      if (wrapped .and. at_line_end) then
         call load_line(unit_no, line, pos, more)
         if (more) then
           if (tokens_left(line, 1) == 1) then

@@ -102,3 +102,41 @@ def test_ingest_one_record_per_line_with_extra_columns_and_blank_lines(tmp_path,
     assert np.array_equal(gas[:, :8], rows[~is_sink][:, :8]) and sinks.shape[0] == 2
     if variant == "V":
         assert np.array_equal(gas[:, 8:10], rows[~is_sink][:, 8:10])
+
+
+def test_ingest_of_saves_wrapped_four_values_per_line_with_zero_energy_rows(tmp_path):
+    """framing must not depend on the values read: a save wrapped at four values per line puts the 8th value
+    at a line end and alpha alone on the next line -- also for a 9-value row whose energy is 0 (a sink by the format's
+    own rule, [F]:650, but written with an alpha).  Every later record must stay in frame."""
+    rows = _rows(9, n=30, seed=11)
+    nine_valued_zero = 7                                  # a 9-value record with u == 0 in front of ordinary gas rows
+    rows[nine_valued_zero, 6] = 0.0
+    wrapped = tmp_path / "wrapped4.txt"
+    with open(wrapped, "w") as f:
+        f.write("x y z vx vy vz energy mass alpha\n")
+        for k, r in enumerate(rows):
+            vals = r if (r[6] != 0.0 or k == nine_valued_zero) else r[:8]
+            for a in range(0, len(vals), 4):
+                f.write(" " + " ".join(f"{v:.17e}" for v in vals[a:a + 4]) + "\n")
+    out = tmp_path / "back.txt"
+    r = subprocess.run([_host("run_sph_hip"), str(wrapped), "-1", str(out)], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gas, sinks = txtio.read_snapshot(str(out))
+    is_sink = rows[:, 6] == 0.0
+    assert gas.shape[0] == int((~is_sink).sum()) and sinks.shape[0] == int(is_sink.sum()) == 3
+    assert np.array_equal(gas[:, :8], rows[~is_sink][:, :8])
+    assert np.array_equal(sinks[:, :6], rows[is_sink][:, :6]) and np.array_equal(sinks[:, 7], rows[is_sink][:, 7])
+
+
+def test_ingest_rejects_one_value_per_line(tmp_path):
+    """a file with one value per line cannot be framed (8 or 9 values per record?): an error, not a guess"""
+    rows = _rows(9, n=6, seed=12)
+    bad = tmp_path / "one_per_line.txt"
+    with open(bad, "w") as f:
+        f.write("header\n")
+        for r in rows:
+            for v in (r if r[6] != 0.0 else r[:8]):
+                f.write(f" {v:.17e}\n")
+    r = subprocess.run([_host("run_sph_hip"), str(bad), "-1", str(tmp_path / "o.txt")], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r.returncode != 0
+    assert "one value per line" in r.stdout + r.stderr

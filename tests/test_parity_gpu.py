@@ -397,3 +397,37 @@ def test_far_outlier_costs_a_trimmed_grid_not_an_error(capi):
     for f in "x y z vx vy vz u alpha".split():
         assert rel_err(ctx.field(f)[:n], gt["sph_s5_" + f]) <= 1e-10, f
     ctx.close()
+
+
+def test_positions_overwritten_in_steady_state_do_not_run_on_truncated_lists(capi):
+    """in the steady state the list report (longest list) and the grid's box are read one build late.  Positions
+    overwritten through sph_upload_field (not sph_upload) with a configuration whose lists exceed the capacity in place
+    used to be evaluated on truncated lists, and the error appeared only at the NEXT build -- or never, for
+    upload_field, density, download.  Now a field write invalidates the stale reports: the build waits for its own."""
+    from oracle import orc
+    rng = np.random.default_rng(77)
+    n = 4000 + 21
+    pos = rng.uniform(-1, 1, (n, 3)) * np.array([120.0, 120.0, 4.0])
+    gas = {"x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
+           "vx": rng.normal(0, 1, n), "vy": rng.normal(0, 1, n), "vz": rng.normal(0, 1, n),
+           "u": rng.uniform(0.5, 2, n), "m": rng.uniform(0.5, 2, n) * 1e-6, "alpha": rng.uniform(0, 1, n)}
+    sinks = {k: np.zeros(1) for k in "x y z vx vy vz m".split()}
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = ctx.run(3, 1e-4, 0.0)                        # steady state: reports are trusted one build late
+    cap0 = ctx.stats().nlist_capacity
+    dense = dict(gas)
+    for k, s in zip("xyz", (0.12, 0.12, 1.0)):           # the same particles squeezed into 1/70 of the area
+        dense[k] = gas[k] * s
+    for k in "xyz":
+        ctx.upload_field(k, dense[k])
+    ctx.density(); ctx.forces()
+    st = ctx.stats()
+    assert st.nlist_max > cap0 and st.nlist_capacity >= st.nlist_max      # the list was regrown before it was used
+    for k in "vx vy vz u alpha".split():
+        dense[k] = ctx.field(k)
+    o = orc.Oracle(dense, sinks)
+    o.evaluate()
+    for f in ("rho", "ax", "ay", "az", "du", "dalpha"):
+        assert rel_err(ctx.field(f), getattr(o, f)) <= EVAL_TOL, f
+    ctx.close()

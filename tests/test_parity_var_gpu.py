@@ -255,3 +255,33 @@ def test_sinks_outside_the_box_are_culled(capi):
                 assert rel_err(ctx.field(f), g[p + f]) <= 1e-10, (k, f)
     assert dts == list(g["full_dt_seq"])
     ctx.close()
+
+
+def test_upload_of_h_after_an_evaluation_builds_the_list_anew(capi):
+    """density, upload_field(h * 1.5), density.  The short path (only h is newer than the grid) must not
+    measure the growth of h against h_new -- which holds build lengths only after sph_update_h -- and re-flag a list whose
+    margin shell does not cover the uploaded lengths.  Checked against the CPU oracle evaluating the same h, once right
+    after an upload (h_new never written) and once after an update_h (h_new = some older lengths)."""
+    from oracle import orc, orc_v
+    rows = ic.keplerian_disc_var(6000, seed=41)
+    gas, sinks = ic.split_rows(rows)
+    ctx = capi.Context(device=0, variable=True)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    ctx.density(); ctx.forces()
+    for round_ in range(2):
+        builds0, reflags0 = ctx.stats().nlist_builds, ctx.stats().nlist_reflags
+        h15 = ctx.field("h") * 1.5
+        ctx.upload_field("h", h15)
+        ctx.density(); ctx.forces()
+        st = ctx.stats()
+        assert st.nlist_builds == builds0 + 1 and st.nlist_reflags == reflags0      # built, not re-flagged
+        g2 = dict(gas); g2["h"] = h15
+        for k in "x y z vx vy vz u alpha".split():
+            g2[k] = ctx.field(k)
+        o = orc_v.OracleV(g2, sinks, nthreads=orc.max_threads())
+        o.evaluate()
+        for f in ("rho", "omega", "ax", "ay", "az", "du", "dalpha"):
+            assert rel_err(ctx.field(f), getattr(o, f)) <= TOL, (round_, f)
+        # second round: h_new now holds the lengths of an update_h two lists ago
+        ctx.update_h(); ctx.density(); ctx.forces()
+    ctx.close()
