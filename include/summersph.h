@@ -123,6 +123,8 @@ enum sph_kernel_id {
     SPH_K_UPDATE_H,    /* variable-h: calc_smoothing                                          */
     SPH_K_GRAVITY,     /* self-gravity: octree keys, radix tree, node sums, tree walk          */
     SPH_K_GRAV_WALK,   /* self-gravity: the tree walk alone (inside SPH_K_GRAVITY)             */
+    SPH_K_REFLAG,      /* variable-h: the list of the new h derived from the list in place (nlist_v_reflag);
+                          SPH_K_NLIST then counts list BUILDS only                              */
     SPH_K_COUNT
 };
 
@@ -213,6 +215,10 @@ int sph_next_dt(sph_ctx *ctx, double *dt);
  * survivors, as after the reference's pack().  Needs the grid of the current positions (call it after
  * sph_density / sph_forces / sph_kick, before the next sph_drift).                               */
 int sph_accrete_and_cull(sph_ctx *ctx, int64_t *n_removed);
+/* the same, and which particles stayed: d_keep (device, one int32 per particle held BEFORE the call, the caller's order;
+ * 1 = survivor) -- for a caller that keeps per-particle data of its own beside the context (the global numbers of
+ * libsummersph_halo.so) and has to pack() it the same way ([F]:481,554)                                          */
+int sph_accrete_and_cull_keep(sph_ctx *ctx, int32_t *d_keep, int64_t *n_removed);
 /* variable-h only: calc_smoothing ([V]:515-546) on the neighbour structure of the last evaluation */
 int sph_update_h(sph_ctx *ctx);
 /* one iteration of simulate's loop body, [F]:889-916 (variable-h: [V]:1120-1152 incl. the h update): density, forces, kick, drift,

@@ -56,16 +56,25 @@ int sph_halo_set_slabs(sph_halo *h, const double *edges, int32_t migrate_every);
 int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, const double *z,
                     const double *vx, const double *vy, const double *vz,
                     const double *u, const double *m, const double *alpha, const int64_t *gid);
+/* the same for a variable-h context (SPH_FLAG_VARIABLE_H): + the smoothing lengths, the 10th column of the reader
+ * of "SUMMER_SPH - Variable.f90":782                                                                               */
+int sph_halo_upload_v(sph_halo *h, int64_t n, const double *x, const double *y, const double *z,
+                      const double *vx, const double *vy, const double *vz,
+                      const double *u, const double *m, const double *alpha, const double *hsml, const int64_t *gid);
 /* nsteps iterations of the loop body; dt, t in and out as sph_run                                                */
 int sph_halo_run(sph_halo *h, int32_t nsteps, double *dt, double *t);
 int64_t sph_halo_count(const sph_halo *h);         /* owned particles of this rank                                  */
 /* the owned particles (any pointer may be NULL); capacity >= sph_halo_count                                       */
 int sph_halo_download(sph_halo *h, int64_t capacity, double *x, double *y, double *z,
                       double *vx, double *vy, double *vz, double *u, double *m, double *alpha, int64_t *gid);
+int sph_halo_download_v(sph_halo *h, int64_t capacity, double *x, double *y, double *z,
+                        double *vx, double *vy, double *vz, double *u, double *m, double *alpha, double *hsml, int64_t *gid);
 /* every rank's owned particles on `root`, ordered by global number (for a single save file as the reference
  * writes it): collective; on root the arrays hold n_total entries (capacity >= n_total), elsewhere they are unused */
 int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z,
                          double *vx, double *vy, double *vz, double *u, double *m, double *alpha, int64_t *gid);
+int sph_halo_gather_root_v(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z,
+                           double *vx, double *vy, double *vz, double *u, double *m, double *alpha, double *hsml, int64_t *gid);
 
 typedef struct sph_halo_stats {
     int64_t ghosts;        /* ghost particles held after the last exchange                                       */
@@ -74,6 +83,8 @@ typedef struct sph_halo_stats {
     int64_t collectives;   /* all-gathers                                                                         */
     int64_t migrations;    /* migration rounds                                                                    */
     int64_t host_waits;    /* times the host waited for the device inside sph_halo_run                            */
+    int64_t removed;       /* particles of this rank accreted or culled (since creation)                          */
+    int64_t sinks_created; /* sinks created by check_sink_creation (the same on every rank)                       */
 } sph_halo_stats;
 int sph_halo_get_stats(const sph_halo *h, sph_halo_stats *out);
 /* transport check: every rank sends `count` doubles to every rank (itself included) and verifies what arrives;

@@ -13,11 +13,14 @@
 !   ref_driver eval   <ic.txt> <out.bin>
 !   ref_driver traj   <ic.txt> <out.bin> <nsteps> <sph|full>
 !   ref_driver kernel <r.txt>  <out.bin>          (r.txt: count, then r values)
+!   ref_driver time   <ic.txt> <out.bin> <nsteps> <sph|full>    as traj, nothing dumped per step; prints the wall time of
+!                                                  the step loop (ingest excluded): bench.py's cpu_baseline, kind "reference"
 program ref_driver
   use SPH_routines_module
   implicit none
   character(len=512) :: mode, a1, a2, a3, a4
   integer :: ou
+  logical :: timing_only = .false.
 
   call get_command_argument(1, mode)
   call get_command_argument(2, a1)
@@ -33,6 +36,9 @@ program ref_driver
   case ('eval')
     call run_eval(trim(a1))
   case ('traj')
+    call run_traj(trim(a1), trim(a3), trim(a4))
+  case ('time')
+    timing_only = .true.
     call run_traj(trim(a1), trim(a3), trim(a4))
   case ('kernel')
     call run_kernel(trim(a1))
@@ -135,6 +141,7 @@ contains
     real(dp) :: t, dt
     real(dp), allocatable :: dts(:), ns(:)
     integer :: i, k, nsteps
+    integer(8) :: c0, c1, crate
     logical :: full
     character(len=8) :: pre
 
@@ -147,6 +154,7 @@ contains
     dts(0) = dt
     ns(0) = real(size(b), dp)
 
+    call system_clock(c0, crate)
     do k = 1, nsteps
       do i = 1, size(b)
         b(i)%number = i
@@ -182,12 +190,15 @@ contains
       deallocate(root)
       dts(k) = dt
       ns(k) = real(size(b), dp)
+      if (timing_only) cycle
       write(pre, '(A,I0,A)') 's', k, '_'
       call put_gas_state(trim(pre), b)
       call put(trim(pre)//'rho', b%density)
       call put_rates(trim(pre), b, s)
       call put_sinks(trim(pre), s)
     end do
+    call system_clock(c1)
+    if (timing_only) write(*, '(A,ES16.8,A,I0,A,I0)') 'loop_seconds ', real(c1 - c0, dp) / real(crate, dp), ' particles ', int(ns(0)), ' steps ', nsteps
     call put('dt_seq', dts)
     call put('n_seq', ns)
     call put('t_end', [t])

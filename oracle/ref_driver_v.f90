@@ -10,6 +10,8 @@
 !   ref_driver_v eval <ic10.txt> <out.bin> <gamma> <eta> <tol> <maxlen> <scale>
 !   ref_driver_v traj <ic10.txt> <out.bin> <gamma> <eta> <tol> <maxlen> <scale> <nsteps> <sph|full>
 !   ref_driver_v kernel <r_h.txt> <out.bin>      (file: count, then "r h" pairs)
+!   ref_driver_v time <ic10.txt> <out.bin> <gamma> <eta> <tol> <maxlen> <scale> <nsteps> <sph|full>   as traj, nothing dumped per
+!                                                 step; prints the wall time of the step loop (bench.py's cpu_baseline)
 program ref_driver_v
   use SPH_routines_module
   implicit none
@@ -17,6 +19,7 @@ program ref_driver_v
   real(dp) :: gamma, eta, tol, maxlen, scale
   integer :: ou, nsteps
   character(len=16) :: variant
+  logical :: timing_only = .false.
 
   call get_command_argument(1, mode)
   call get_command_argument(2, a1)
@@ -35,6 +38,7 @@ program ref_driver_v
     if (trim(mode) == 'eval') then
       call run_eval(trim(a1))
     else
+      timing_only = trim(mode) == 'time'
       call get_command_argument(9, arg); read(arg, *) nsteps
       call get_command_argument(10, variant)
       call run_traj(trim(a1), nsteps, trim(variant) == 'full')
@@ -130,6 +134,7 @@ contains
     real(dp) :: t, dt
     real(dp), allocatable :: dts(:), ns(:)
     integer :: i, k
+    integer(8) :: c0, c1, crate
     character(len=8) :: pre
 
     call read_data_from_file(icfile, b, s)
@@ -138,6 +143,7 @@ contains
     dt = 1.0e-2_dp
     dts(0) = dt
     ns(0) = real(size(b), dp)
+    call system_clock(c0, crate)
     do k = 1, nsteps
       do i = 1, size(b)
         b(i)%number = i
@@ -175,6 +181,7 @@ contains
       deallocate(root)
       dts(k) = dt
       ns(k) = real(size(b), dp)
+      if (timing_only) cycle
       write(pre, '(A,I0,A)') 's', k, '_'
       call put_state(trim(pre), b)
       call put(trim(pre)//'rho', b%density)
@@ -182,6 +189,8 @@ contains
       call put_rates(trim(pre), b, s)
       call put_sinks(trim(pre), s)
     end do
+    call system_clock(c1)
+    if (timing_only) write(*, '(A,ES16.8,A,I0,A,I0)') 'loop_seconds ', real(c1 - c0, dp) / real(crate, dp), ' particles ', int(ns(0)), ' steps ', nsteps
     call put('dt_seq', dts)
     call put('n_seq', ns)
     call put('t_end', [t])

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 passes of profiles/r02_profile.sh into
-   profiles/r02_<workload>_summary.txt   kernel table + counters per launch (text, for reading)
-   profiles/r02_limiters.json            per workload and kernel: duration, HBM traffic, TA / vector-issue / LDS occupancy
-bench.py quotes the JSON in its roofline objects (traffic, limiter), so every number in the bench line can be recomputed
-from a file in this directory.
+"""Turns the rocprofv3 passes of profiles/profile.sh into
+   profiles/<round>_<workload>_summary.txt   kernel table + counters per launch (text, for reading)
+   profiles/<round>_limiters.json            per workload and kernel: duration, HBM traffic, TA / vector-issue / LDS occupancy;
+                                             "_meta": sha256 of the kernel sources the passes were taken on (bench.csrc_sha256)
+bench.py quotes the newest JSON in its roofline objects (traffic, limiter) and marks the quote stale when the kernel sources
+have changed since, so every number in the bench line can be recomputed from a file in this directory.
 
-    python3 profiles/make_limiters.py gpurun_out/<tag> fixed variable full
+    python3 profiles/make_limiters.py r03 gpurun_out/<tag> fixed variable full
 
 Formulas (MI355X: 256 CUs = 256 TAs = 256 LDS, 1024 SIMDs, 32 shader engines):
   cycles      = SQ_BUSY_CYCLES / 32                     (the kernel's duration in shader clocks)
@@ -51,10 +52,23 @@ def counters(d):
 
 
 def main():
-    base = sys.argv[1]
-    workloads = sys.argv[2:] or ["fixed", "variable", "full"]
-    path = os.path.join(ROOT, "profiles", "r02_limiters.json")
+    rnd, base = sys.argv[1], sys.argv[2]
+    workloads = sys.argv[3:] or ["fixed", "variable", "full"]
+    path = os.path.join(ROOT, "profiles", f"{rnd}_limiters.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.csrc_sha256()
+    if out.get("_meta", {}).get("csrc_sha256") not in (None, sha):
+        out = {}                                        # passes of different code are not mixed in one file
+    git = None
+    try:
+        import subprocess
+        git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        pass
+    out["_meta"] = {"csrc_sha256": sha, "git": git or out.get("_meta", {}).get("git"),
+                    "note": "git = HEAD of the tree the passes ran on when known (the GPU box has no .git: see the commit that adds this file)"}
     for w in workloads:
         o = f"{base}_{w}"
         stats = rows(o + "_kt", "*kernel_stats.csv")
@@ -100,8 +114,8 @@ def main():
             if info["pct"] >= 0.5:
                 parts = [f"{x}={e[x]:.3g}" for x in ("traffic_bytes_per_launch", "valu_issue", "valu_active", "ta_busy", "lds_busy", "clock_GHz_est") if x in e]
                 lines.append(f"{k:70s} " + "  ".join(parts))
-        out[w] = {"command": open(o + "_kt.log").read()[:0] or f"bash profiles/r02_profile.sh <tag> {w}", "kernels": rec}
-        with open(os.path.join(ROOT, "profiles", f"r02_{w}_summary.txt"), "w") as fh:
+        out[w] = {"command": f"bash profiles/profile.sh {rnd} <tag> {w}", "kernels": rec}
+        with open(os.path.join(ROOT, "profiles", f"{rnd}_{w}_summary.txt"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
         print("\n".join(lines[:14]))
     with open(path, "w") as fh:

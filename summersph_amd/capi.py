@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SUMMERSPH_LIB", LIB_PATH)      # A/B builds of the sa
 _D = C.POINTER(C.c_double)
 
 FIELDS = ["x", "y", "z", "vx", "vy", "vz", "u", "m", "alpha", "rho", "P", "c", "ax", "ay", "az", "du", "dalpha", "h", "omega"]
-KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h", "gravity", "grav_walk"]
+KERNELS = ["grid", "nlist", "density", "forces", "sinkacc", "kick", "drift", "dt", "leaf", "update_h", "gravity", "grav_walk", "reflag"]
 FLAG_REUSE_DENSITY = 1
 FLAG_VARIABLE_H = 2
 FLAG_NO_LDS_TILES = 4

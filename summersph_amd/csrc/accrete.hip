@@ -250,7 +250,7 @@ __global__ __launch_bounds__(AB) void acc_compact(CompactArgs a, const int32_t *
 
 // requires a valid grid (bbox, drec, orig/inv of the current positions).  On return the context holds only
 // the survivors, in the caller's order (like a fresh upload); *removed = how many particles left.
-int accrete_and_cull(sph_ctx *c, int64_t *removed) {
+int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     const int64_t n = c->n;
     *removed = 0;
     if (n == 0) return SPH_OK;
@@ -289,6 +289,7 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed) {
     acc_mark<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, drec, c->orig, c->sink, c->sink_radius, c->ns,
                                                    c->variable ? 1 : 0, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
     AC_CHECK(hipGetLastError());
+    if (d_keep_out) AC_CHECK(hipMemcpyAsync(d_keep_out, keep, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
     if (any_mass) {
         const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
         for (int k = 0; k < c->ns; k++) {

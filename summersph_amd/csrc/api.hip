@@ -179,11 +179,9 @@ int do_density(sph_ctx *c) {
         API_TRY(varh_h_stats(c, c->h_new_is_build));
         c->h_new_is_build = false;
         { Timed t(c, SPH_K_LEAF); API_TRY(varh_refresh_h(c)); }
-        {   // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built
-            Timed t(c, SPH_K_NLIST);
-            if (varh_can_reflag(c)) API_TRY(varh_nlist_reflag(c));
-            else API_TRY(varh_nlist_build(c));
-        }
+        // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built
+        if (varh_can_reflag(c)) { Timed t(c, SPH_K_REFLAG); API_TRY(varh_nlist_reflag(c)); }
+        else { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
         c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
         c->grid_valid = true;
     }
@@ -336,7 +334,7 @@ int do_update_h(sph_ctx *c) {
     return SPH_OK;
 }
 
-int do_accrete(sph_ctx *c, int64_t *removed) {
+int do_accrete(sph_ctx *c, int64_t *removed, int32_t *d_keep = nullptr) {
     if (!c->order_valid) { c->err = "sph_accrete_and_cull: needs the grid of the current positions (call sph_density first)"; return SPH_ERR_STATE; }
     if (c->n_owned != c->n) { c->err = "sph_accrete_and_cull: not available with ghost particles"; return SPH_ERR_STATE; }
     if (!c->bbox_exact) {       // the octree's root box is the exact bounding box: take it from the last build's read-back slot
@@ -345,7 +343,8 @@ int do_accrete(sph_ctx *c, int64_t *removed) {
         for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
         c->bbox_exact = true;
     }
-    API_TRY(accrete_and_cull(c, removed));
+    API_TRY(accrete_and_cull(c, removed, d_keep));
+    if (*removed > 0) c->numbers_set = false;           // the caller's numbering changed with the pack()
     return sinks_cull(c);                               // Variable.f90:610-613 (after the accretion, like the gas cull)
 }
 
@@ -789,6 +788,15 @@ int sph_accrete_and_cull(sph_ctx *c, int64_t *n_removed) {
     DeviceGuard g(c->device);
     int64_t r = 0;
     const int st = do_accrete(c, &r);
+    if (n_removed) *n_removed = r;
+    return st;
+}
+
+int sph_accrete_and_cull_keep(sph_ctx *c, int32_t *d_keep, int64_t *n_removed) {
+    if (!c || (c->n > 0 && !d_keep)) return SPH_ERR_ARG;
+    DeviceGuard g(c->device);
+    int64_t r = 0;
+    const int st = do_accrete(c, &r, d_keep);
     if (n_removed) *n_removed = r;
     return st;
 }

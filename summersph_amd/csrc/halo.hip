@@ -1,13 +1,15 @@
 // halo.hip -- libsummersph_halo.so: the loop body of simulate() on several GPUs without Python (include/summersph_halo.h).
 //
 // A client of the public C ABI (include/summersph.h) only: every physics kernel is the context's; this file owns the
-// orchestration of summersph_amd/dist.py (DistSim._step / evaluate / _exchange_ghosts / _migrate / _reduce, fixed h,
-// no self-gravity) and the two transports it runs on.  Streams: s0 = the context's stream (set with sph_set_stream, so
+// orchestration of summersph_amd/dist.py (DistSim._step / evaluate / _exchange_ghosts / _migrate / _reduce /
+// _gravity_sources / _accrete_and_cull: fixed h and variable h, Barnes-Hut self-gravity on the replicated tree, sink
+// accretion + cull, sink creation) and the two transports it runs on.  Streams: s0 = the context's stream (set with sph_set_stream, so
 // the *_dev calls do not synchronise), s1 = the communication stream.  Every message is packed on s0, an event lets
 // s1 start, the grouped ncclSend / ncclRecv (or the all-gather) runs on s1, a second event lets s0 unpack -- and s0
 // keeps computing between the two events (density, the interior wavefronts of the forces).
 //
-// The reference (/root/reference/SUMMER_SPH.f90:863-930) is one process; the step sequence reproduced is [F]:889-916.
+// The reference (/root/reference/SUMMER_SPH.f90:863-930) is one process; the step sequence reproduced is [F]:889-920
+// ("SUMMER_SPH - Variable.f90":1120-1158 for variable-h contexts).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <rocprim/device/device_select.hpp>
@@ -28,9 +30,10 @@
 namespace {
 
 constexpr int MAXP = 64;                 // sph_select_boxes takes 64 boxes
-constexpr int NF = 9;
+constexpr int NF_MAX = 10;               // state fields that travel: 9, + h for variable-h contexts
 constexpr int DT_SLOT = 192, PRED_SLOT = 193;
-const int32_t STATE[NF] = {SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA};
+constexpr int ACC_PARTIALS = 7 * 64;     // SPH_ACC_PARTIALS: per sink m, m x, m y, m z, m vx, m vy, m vz of the accreted particles
+const int32_t STATE[NF_MAX] = {SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_M, SPH_F_ALPHA, SPH_F_H};
 
 struct DevGuard {
     int prev = 0;
@@ -220,6 +223,31 @@ __global__ void pattern_kernel(double *p, int64_t n, double base) {
     if (k < n) p[k] = base + (double)k;
 }
 
+// largest of n positive doubles -> *out (bit patterns of positive doubles order like unsigned integers); *out zeroed before
+__global__ void max_positive(const double *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double m = i < n ? v[i] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ void set_header(double *p, double count) { if (threadIdx.x == 0) { p[0] = count; p[1] = 0.0; } }
+
+// {x,y,z,m} records of one rank's block of the all-gathered sources: src[(off + k) * 4 + f] = blk[f * cnt + k]
+__global__ void source_records(const double *__restrict__ blk, int64_t cnt, int64_t off, double *__restrict__ src) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    for (int f = 0; f < 4; f++) src[(off + k) * 4 + f] = blk[(int64_t)f * cnt + k];
+}
+
+// the candidate with the lowest particle number (first among equals, as torch.argmin): row of 9 doubles
+__global__ void pick_candidate(const double *__restrict__ all, int P, double *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    int best = 0;
+    for (int q = 1; q < P; q++) if (all[(size_t)q * 9] < all[(size_t)best * 9]) best = q;
+    for (int k = 0; k < 9; k++) out[k] = all[(size_t)best * 9 + k];
+}
+
 inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -232,12 +260,19 @@ struct sph_halo {
     bool own_s1 = true;
     hipEvent_t e01 = nullptr, e10 = nullptr, e_pred = nullptr;
     double h = 0.0;
+    bool variable = false, gravity = false, accrete = false, sink_creation = false;   // the context's flags
+    bool octree = false;                 // gravity || variable: the shared octree needs every rank's exact box and all particles
+    int nf = 9;                          // state fields per particle (10 with h)
+    int64_t counts_all[MAXP];            // owned particles of every rank
+    bool counts_valid = false, sources_valid = false;
+    std::vector<double> last_boxes;      // every rank's exact owned box at the last ghost exchange (host)
     Edges edges{};
     int migrate_every = 32, since_migrate = 0;
     int64_t n_owned = 0, reserved = 0;
     bool uploaded = false;
     bool pos_dirty = true, vel_dirty = false, dt_pending = false, pred_for_drift = false, pred_valid = false;
     DevBuf gid, gid_new, own, newbuf, part, allpart, row, box, boxes, cnt, cntall, ghosts, dest, flags, keep_ids, sel_tmp, sel_count;
+    DevBuf src, srcmine, srcall, accp, accall, keep, cand, candall, gnum;
     DevBuf sendb[MAXP], recvb[MAXP], ids[MAXP];
     double *pin = nullptr;               // pinned host memory: the gathered partials, the boxes, the count matrix
     double *pin_part = nullptr, *pin_boxes = nullptr;
@@ -247,7 +282,7 @@ struct sph_halo {
     double *pin_hdr = nullptr;               // pinned: headers out [0, P), headers in [P, 2P)
     bool refresh_pending = false;
     int refresh_nf = 0;
-    int32_t refresh_fields[NF];
+    int32_t refresh_fields[NF_MAX];
     sph_halo_stats st{};
     std::string err;
 };
@@ -288,8 +323,15 @@ int common_init(sph_halo *h) {
     if (h->P < 1 || h->P > MAXP || h->rank < 0 || h->rank >= h->P) { h->err = "1 <= nranks <= 64, 0 <= rank < nranks"; return SPH_ERR_ARG; }
     sph_params p;
     H_TRY(sph_get_params(h->c, &p));
-    if (p.flags & (SPH_FLAG_VARIABLE_H | SPH_FLAG_SELF_GRAVITY | SPH_FLAG_ACCRETE_CULL | SPH_FLAG_SINK_CREATION)) {
-        h->err = "sph_halo: fixed-h contexts without self-gravity, accretion or sink creation (the octree paths: summersph_amd/dist.py)";
+    h->variable = (p.flags & SPH_FLAG_VARIABLE_H) != 0;
+    h->gravity = (p.flags & SPH_FLAG_SELF_GRAVITY) != 0;
+    h->accrete = (p.flags & SPH_FLAG_ACCRETE_CULL) != 0;
+    h->sink_creation = (p.flags & SPH_FLAG_SINK_CREATION) != 0 && h->variable;
+    h->octree = h->gravity || h->variable;
+    h->nf = h->variable ? 10 : 9;
+    if (h->accrete && h->P > 1 && !h->octree) {
+        // the accretion test walks the octree of ALL particles: it needs the all-gathered sources of the self-gravity path
+        h->err = "sph_halo: accretion on several ranks needs SPH_FLAG_SELF_GRAVITY or SPH_FLAG_VARIABLE_H (the shared octree)";
         return SPH_ERR_ARG;
     }
     h->h = p.h;
@@ -304,14 +346,14 @@ int common_init(sph_halo *h) {
     H_HIP(hipEventCreateWithFlags(&h->e_pred, hipEventDisableTiming));
     H_TRY(sph_set_stream(h->c, h->s0));
     H_TRY(sph_set_rank(h->c, h->rank, h->P));
-    const size_t nd = (size_t)h->P * (SPH_PARTIALS + 6) + (size_t)h->P * h->P + h->P + 64 + 4 * (size_t)h->P;
+    const size_t nd = (size_t)h->P * (SPH_PARTIALS + 8) + (size_t)h->P * h->P + h->P + 64 + 4 * (size_t)h->P;
     H_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin), nd * sizeof(double), hipHostMallocDefault));
     h->pin_part = h->pin;
     h->pin_boxes = h->pin_part + (size_t)h->P * SPH_PARTIALS;
-    h->pin_cnt = reinterpret_cast<int64_t *>(h->pin_boxes + (size_t)h->P * 6);
+    h->pin_cnt = reinterpret_cast<int64_t *>(h->pin_boxes + (size_t)h->P * 8);
     h->pin_row = h->pin_cnt + (size_t)h->P * h->P;
     h->pin_hdr = reinterpret_cast<double *>(h->pin_row + h->P + 8);
-    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_first[q] = 0; h->ghost_count[q] = 0; h->cap_send[q] = 0; h->cap_recv[q] = 0; }
+    for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_first[q] = 0; h->ghost_count[q] = 0; h->cap_send[q] = 0; h->cap_recv[q] = 0; h->counts_all[q] = 0; }
     h->edges.n = 0;
     return SPH_OK;
 }
@@ -370,7 +412,7 @@ int ensure_reserve(sph_halo *h, int64_t n) {
 
 // particles that left their slab change owner (dist.py _migrate)
 int migrate(sph_halo *h) {
-    const int P = h->P;
+    const int P = h->P, NF = h->nf;
     const int64_t n = h->n_owned;
     h->st.migrations++;
     H_HIP(h->own.need((size_t)std::max<int64_t>(n, 1) * NF * 8));
@@ -446,19 +488,24 @@ int migrate(sph_halo *h) {
     if (int st = ensure_reserve(h, n_new)) return st;
     const double *r = h->newbuf.as<double>();
     H_TRY(sph_upload_dev(h->c, n_new, r, r + n_new, r + 2 * n_new, r + 3 * n_new, r + 4 * n_new, r + 5 * n_new, r + 6 * n_new, r + 7 * n_new, r + 8 * n_new));
+    if (h->variable && n_new > 0) H_TRY(sph_upload_field_dev(h->c, SPH_F_H, r + 9 * n_new, n_new));
     std::swap(h->gid, h->gid_new);
     h->n_owned = n_new;
     h->st.migrated += moved;
+    h->counts_valid = false; h->sources_valid = false;
     for (int q = 0; q < P; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; }
     return SPH_OK;
 }
 
 // who needs which of my particles, ship them, swap them in (dist.py _exchange_ghosts)
 int exchange_ghosts(sph_halo *h) {
-    const int P = h->P;
-    bool use_pred = h->pred_for_drift && h->pred_valid;
+    const int P = h->P, NF = h->nf;
+    const int W = NF + (h->variable ? 1 : 0);       // variable h: + the global particle number of every ghost ([V]:383 compares numbers)
+    // the octree paths (self-gravity, variable h) need the exact global box: no predicted boxes for them
+    bool use_pred = h->pred_for_drift && h->pred_valid && !h->octree;
     h->pred_for_drift = false;
     std::vector<double> boxes((size_t)P * 6);
+    double hmax_all = 0.0;
     if (use_pred) {
         H_HIP(hipEventSynchronize(h->e_pred));
         h->st.host_waits++;
@@ -470,17 +517,31 @@ int exchange_ghosts(sph_halo *h) {
             }
     }
     if (!use_pred) {
-        H_HIP(h->box.need(6 * 8));
-        H_HIP(h->boxes.need((size_t)P * 6 * 8));
+        // every rank's box (variable h: and its largest h -- i and j interact within 2 max(h_i, h_j), so the ghost layer is as
+        // wide as twice the largest h anywhere): 8 doubles per rank
+        H_HIP(h->box.need(8 * 8));
+        H_HIP(h->boxes.need((size_t)P * 8 * 8));
+        H_HIP(hipMemsetAsync(h->box.p, 0, 8 * 8, h->s0));
         H_TRY(sph_owned_bbox(h->c, nullptr, h->box.as<double>()));
+        if (h->variable && h->n_owned > 0) {
+            static const int32_t HF[1] = {SPH_F_H};
+            H_HIP(h->own.need((size_t)h->n_owned * 8));
+            H_TRY(sph_gather_fields_dev(h->c, 1, HF, h->n_owned, nullptr, h->own.as<double>()));
+            max_positive<<<blocks_for(h->n_owned), 256, 0, h->s0>>>(h->own.as<double>(), h->n_owned, reinterpret_cast<unsigned long long *>(h->box.as<double>() + 6));
+            H_HIP(hipGetLastError());
+        }
         if (int st = s0_then_s1(h)) return st;
-        H_TR(h->tr->allgather(h->box.p, h->boxes.p, 6 * 8, h->s1));
+        H_TR(h->tr->allgather(h->box.p, h->boxes.p, 8 * 8, h->s1));
         h->st.collectives++;
-        H_HIP(hipMemcpyAsync(h->pin_boxes, h->boxes.p, (size_t)P * 6 * 8, hipMemcpyDeviceToHost, h->s1));
+        H_HIP(hipMemcpyAsync(h->pin_boxes, h->boxes.p, (size_t)P * 8 * 8, hipMemcpyDeviceToHost, h->s1));
         if (int st = host_wait(h, h->s1)) return st;
-        for (int k = 0; k < P * 6; k++) boxes[k] = h->pin_boxes[k];
+        for (int q = 0; q < P; q++) {
+            for (int a = 0; a < 6; a++) boxes[(size_t)q * 6 + a] = h->pin_boxes[(size_t)q * 8 + a];
+            hmax_all = std::max(hmax_all, h->pin_boxes[(size_t)q * 8 + 6]);
+        }
+        h->last_boxes = boxes;
     }
-    const double r = 2.0 * h->h * (1.0 + 1e-9);
+    const double r = 2.0 * (h->variable ? hmax_all : h->h) * (1.0 + 1e-9);
     auto finite6 = [&](int q) { for (int a = 0; a < 6; a++) if (!std::isfinite(boxes[(size_t)q * 6 + a])) return false; return true; };
     const bool mine_ok = finite6(h->rank);
     const double *me = &boxes[(size_t)h->rank * 6];
@@ -505,9 +566,15 @@ int exchange_ghosts(sph_halo *h) {
     }
     // The selection does not wait for its counts (sph_select_boxes_async): the payload is packed for the agreed room by a
     // kernel that reads the count on the device, and the host learns both its own counts and the peers' at the one wait below.
+    // (The octree paths wait for their counts -- sph_select_boxes -- because the ghosts' global numbers travel as an extra row
+    // that is packed from this object's own list; they wait for the exact boxes anyway.)
+    const bool sync_select = h->variable;
     int64_t counts[MAXP], selc[MAXP];
     for (int q = 0; q < P; q++) counts[q] = 0;
-    if (npeers > 0) H_TRY(sph_select_boxes_async(h->c, npeers, sel));
+    if (npeers > 0) {
+        if (sync_select) { H_TRY(sph_select_boxes(h->c, npeers, sel, selc)); h->st.host_waits++; }
+        else H_TRY(sph_select_boxes_async(h->c, npeers, sel));
+    }
     // The payload travels without a size exchange: both sides of a pair agree on the room the message has (cap_send here =
     // cap_recv there, derived from the count of the last message between the two, 0 at first), the first two doubles say
     // how many particles there are.  Round A: header + rows in that room.  Round B, for the pairs whose count did not fit
@@ -520,13 +587,33 @@ int exchange_ghosts(sph_halo *h) {
     void *rp[MAXP];
     size_t sb[MAXP], rb[MAXP];
     for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rb[q] = 0; }
+    // rows of a message of `cnt` particles behind the 2-double header: NF state rows [+ the numbers], row stride cnt
+    auto pack_rows = [&](int q, int64_t cnt, double *dst) -> int {
+        H_TRY(sph_gather_fields_dev(h->c, NF, STATE, cnt, h->ids[q].as<int64_t>(), dst));
+        if (W > NF) {
+            gid_to_double<<<blocks_for(cnt), 256, 0, h->s0>>>(h->gid.as<int64_t>(), h->ids[q].as<int64_t>(), cnt, dst + (size_t)NF * cnt);
+            H_HIP(hipGetLastError());
+        }
+        return SPH_OK;
+    };
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
-        H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * std::max<int64_t>(h->cap_send[q], 1)) * 8));
-        H_HIP(h->recvb[q].need((size_t)(2 + NF * h->cap_recv[q]) * 8));
-        H_TRY(sph_gather_selected_dev(h->c, b, NF, STATE, h->cap_send[q], h->sendb[q].as<double>()));
-        sp[q] = h->sendb[q].p; sb[q] = (size_t)(2 + NF * h->cap_send[q]) * 8;
-        rp[q] = h->recvb[q].p; rb[q] = (size_t)(2 + NF * h->cap_recv[q]) * 8;
+        H_HIP(h->sendb[q].need((size_t)(2 + (W + 1) * std::max<int64_t>(h->cap_send[q], 1)) * 8));
+        H_HIP(h->recvb[q].need((size_t)(2 + W * h->cap_recv[q]) * 8));
+        if (sync_select) {
+            counts[q] = selc[b];
+            set_header<<<1, 64, 0, h->s0>>>(h->sendb[q].as<double>(), (double)counts[q]);
+            H_HIP(hipGetLastError());
+            if (counts[q] > 0) {
+                H_HIP(h->ids[q].need((size_t)counts[q] * 8));
+                H_TRY(sph_selected_ids_dev(h->c, b, counts[q], h->ids[q].as<int64_t>()));
+                if (counts[q] <= h->cap_send[q]) if (int st = pack_rows(q, counts[q], h->sendb[q].as<double>() + 2)) return st;
+            }
+        } else {
+            H_TRY(sph_gather_selected_dev(h->c, b, NF, STATE, h->cap_send[q], h->sendb[q].as<double>()));
+        }
+        sp[q] = h->sendb[q].p; sb[q] = (size_t)(2 + W * h->cap_send[q]) * 8;
+        rp[q] = h->recvb[q].p; rb[q] = (size_t)(2 + W * h->cap_recv[q]) * 8;
     }
     if (int st = s0_then_s1(h)) return st;
     if (int st = p2p_raw(h, sp, sb, rp, rb)) return st;
@@ -534,7 +621,7 @@ int exchange_ghosts(sph_halo *h) {
     for (int b = 0; b < npeers; b++)
         H_HIP(hipMemcpyAsync(hdr_in + peers[b], h->recvb[peers[b]].p, 8, hipMemcpyDeviceToHost, h->s1));
     if (npeers > 0) if (int st = host_wait(h, h->s1)) return st;
-    if (npeers > 0) {
+    if (npeers > 0 && !sync_select) {
         H_TRY(sph_selected_counts(h->c, npeers, selc));        // they arrived before the headers (same wait)
         for (int b = 0; b < npeers; b++) counts[peers[b]] = selc[b];
     }
@@ -544,7 +631,7 @@ int exchange_ghosts(sph_halo *h) {
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
         h->send_count[q] = counts[q];
-        if (counts[q] == 0) continue;
+        if (counts[q] == 0 || sync_select) continue;
         H_HIP(h->ids[q].need((size_t)counts[q] * 8));
         H_TRY(sph_selected_ids_dev(h->c, b, counts[q], h->ids[q].as<int64_t>()));
     }
@@ -554,14 +641,14 @@ int exchange_ghosts(sph_halo *h) {
     for (int b = 0; b < npeers; b++) {
         const int q = peers[b];
         if (counts[q] > h->cap_send[q]) {
-            H_HIP(h->sendb[q].need((size_t)(2 + (NF + 1) * counts[q]) * 8));      // (re-allocation waits for the device: round A is complete)
-            H_TRY(sph_gather_fields_dev(h->c, NF, STATE, counts[q], h->ids[q].as<int64_t>(), h->sendb[q].as<double>() + 2));
-            sp[q] = h->sendb[q].as<double>() + 2; sb[q] = (size_t)NF * counts[q] * 8;
+            H_HIP(h->sendb[q].need((size_t)(2 + (W + 1) * counts[q]) * 8));      // (re-allocation waits for the device: round A is complete)
+            if (int st = pack_rows(q, counts[q], h->sendb[q].as<double>() + 2)) return st;
+            sp[q] = h->sendb[q].as<double>() + 2; sb[q] = (size_t)W * counts[q] * 8;
             resend = true;
         }
         if (rc[q] > h->cap_recv[q]) {
-            H_HIP(h->recvb[q].need((size_t)NF * rc[q] * 8));
-            rp[q] = h->recvb[q].p; rb[q] = (size_t)NF * rc[q] * 8;
+            H_HIP(h->recvb[q].need((size_t)W * rc[q] * 8));
+            rp[q] = h->recvb[q].p; rb[q] = (size_t)W * rc[q] * 8;
             roff[q] = 0;
         }
         h->cap_send[q] = ghost_capacity(counts[q]);
@@ -580,20 +667,77 @@ int exchange_ghosts(sph_halo *h) {
         h->err = "sph_halo: more ghosts than the reserved slots hold (n_owned + ghosts > n_owned * 5/4 + 65536)";
         return SPH_ERR_NOMEM;
     }
-    H_HIP(h->ghosts.need((size_t)std::max<int64_t>(total, 1) * NF * 8));
+    H_HIP(h->ghosts.need((size_t)std::max<int64_t>(total, 1) * W * 8));
     int64_t first = h->n_owned, off = 0;
     for (int q = 0; q < P; q++) {
         h->ghost_first[q] = first;
         h->ghost_count[q] = rc[q];
         if (rc[q] > 0) {
-            gather_rows<<<blocks_for(rc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>() + roff[q], rc[q], nullptr, rc[q], NF, h->ghosts.as<double>(), total, off);
+            gather_rows<<<blocks_for(rc[q]), 256, 0, h->s0>>>(h->recvb[q].as<double>() + roff[q], rc[q], nullptr, rc[q], W, h->ghosts.as<double>(), total, off);
             H_HIP(hipGetLastError());
         }
         first += rc[q];
         off += rc[q];
     }
     h->st.ghosts = total;
-    H_TRY(sph_replace_ghosts_dev(h->c, total, h->ghosts.as<double>()));
+    H_TRY(sph_replace_ghosts_dev(h->c, total, h->ghosts.as<double>()));        // rows 0 .. NF-1 (row stride `total`)
+    if (h->variable) {
+        // the pair rule of [V]:383 compares the reference's particle numbers: the owned particles' and the ghosts'
+        if (h->n_owned > 0) H_TRY(sph_set_numbers_dev(h->c, 0, h->n_owned, h->gid.as<int64_t>()));
+        if (total > 0) {
+            H_HIP(h->gnum.need((size_t)total * 8));
+            double_to_gid<<<blocks_for(total), 256, 0, h->s0>>>(h->ghosts.as<double>() + (size_t)NF * total, total, h->gnum.as<int64_t>());
+            H_HIP(hipGetLastError());
+            H_TRY(sph_set_numbers_dev(h->c, h->n_owned, total, h->gnum.as<int64_t>()));
+        }
+    }
+    return SPH_OK;
+}
+
+// Self-gravity is long range, and the variable-h neighbour rule needs the octree leaf of every particle: every rank gets
+// {x, y, z, m} of ALL particles (one all-gather, padded to the largest rank) and builds the same octree as the undecomposed
+// run would -- same particles, same root box, hence the same nodes and the same accepted set for every target -- and walks it
+// for its own particles.  The tree build is replicated work; the walk, which dominates, is shared.  (dist.py _gravity_sources)
+int gravity_sources(sph_halo *h) {
+    static const int32_t XYZM[4] = {SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_M};
+    const int P = h->P;
+    if (!h->counts_valid) {
+        H_HIP(h->cnt.need((size_t)std::max(P, 2) * 8));
+        H_HIP(h->cntall.need((size_t)P * P * 8));
+        h->pin_row[0] = h->n_owned;
+        H_HIP(hipMemcpyAsync(h->cnt.p, h->pin_row, 8, hipMemcpyHostToDevice, h->s1));
+        H_TR(h->tr->allgather(h->cnt.p, h->cntall.p, 8, h->s1));
+        h->st.collectives++;
+        H_HIP(hipMemcpyAsync(h->pin_cnt, h->cntall.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->s1));
+        if (int st = host_wait(h, h->s1)) return st;
+        for (int q = 0; q < P; q++) h->counts_all[q] = h->pin_cnt[q];
+        h->counts_valid = true;
+    }
+    int64_t maxn = 1, total = 0;
+    for (int q = 0; q < P; q++) { maxn = std::max(maxn, h->counts_all[q]); total += h->counts_all[q]; }
+    const size_t blk = (size_t)4 * maxn * 8;
+    H_HIP(h->srcmine.need(blk));
+    H_HIP(h->srcall.need(blk * P));
+    H_HIP(h->src.need((size_t)std::max<int64_t>(total, 1) * 4 * 8));
+    if (h->n_owned > 0) H_TRY(sph_gather_fields_dev(h->c, 4, XYZM, h->n_owned, nullptr, h->srcmine.as<double>()));     // [4][n_owned], compact
+    if (int st = s0_then_s1(h)) return st;
+    H_TR(h->tr->allgather(h->srcmine.p, h->srcall.p, blk, h->s1));
+    h->st.collectives++;
+    if (int st = s1_then_s0(h)) return st;
+    int64_t off = 0;
+    double lo_hi[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int q = 0; q < P; q++) {
+        const int64_t cq = h->counts_all[q];
+        if (cq == 0) continue;
+        source_records<<<blocks_for(cq), 256, 0, h->s0>>>(h->srcall.as<double>() + (size_t)q * 4 * maxn, cq, off, h->src.as<double>());
+        H_HIP(hipGetLastError());
+        off += cq;
+        for (int a = 0; a < 3; a++) {
+            lo_hi[a] = std::min(lo_hi[a], h->last_boxes[(size_t)q * 6 + a]);
+            lo_hi[3 + a] = std::max(lo_hi[3 + a], h->last_boxes[(size_t)q * 6 + 3 + a]);
+        }
+    }
+    H_TRY(sph_set_gravity_sources_dev(h->c, total, h->src.as<double>(), lo_hi));
     return SPH_OK;
 }
 
@@ -631,7 +775,7 @@ int refresh_finish(sph_halo *h) {
 int reduce_start(sph_halo *h, bool before_drift) {
     H_HIP(h->part.need(SPH_PARTIALS * 8));
     // the predicted box costs a pass over the particles: only where a drift follows and other ranks read it
-    H_TRY(sph_pack_partials_ex_dev(h->c, h->part.as<double>(), (before_drift && h->P > 1) ? 1 : 0));
+    H_TRY(sph_pack_partials_ex_dev(h->c, h->part.as<double>(), (before_drift && h->P > 1 && !h->octree) ? 1 : 0));
     if (h->P > 1) {
         H_HIP(h->allpart.need((size_t)h->P * SPH_PARTIALS * 8));
         if (int st = s0_then_s1(h)) return st;
@@ -651,7 +795,7 @@ int reduce_finish(sph_halo *h, bool before_drift) {
     } else {
         H_HIP(hipStreamWaitEvent(h->s0, h->e_pred, 0));
         H_TRY(sph_apply_partials_dev(h->c, h->allpart.as<double>(), h->P, SPH_PARTIALS, h->dt_pending ? 1 : 0));
-        h->pred_valid = before_drift;
+        h->pred_valid = before_drift && !h->octree;
     }
     h->dt_pending = false;
     return SPH_OK;
@@ -659,7 +803,7 @@ int reduce_finish(sph_halo *h, bool before_drift) {
 
 // one force evaluation: create_tree .. find_forces of the reference, [F]:894-898 (dist.py evaluate)
 int evaluate(sph_halo *h, bool before_drift) {
-    static const int32_t RHO[1] = {SPH_F_RHO};
+    static const int32_t RHO[2] = {SPH_F_RHO, SPH_F_OMEGA};
     static const int32_t VEL[5] = {SPH_F_VX, SPH_F_VY, SPH_F_VZ, SPH_F_U, SPH_F_ALPHA};
     const bool multi = h->P > 1;
     if (h->pos_dirty) {
@@ -669,24 +813,107 @@ int evaluate(sph_halo *h, bool before_drift) {
             h->pred_for_drift = false;          // ownership changed: the predicted boxes are void
         }
         if (multi) if (int st = exchange_ghosts(h)) return st;
+        if (multi && h->octree && !h->sources_valid) {
+            if (int st = gravity_sources(h)) return st;
+            h->sources_valid = true;
+        }
+        if (!multi && h->variable && h->n_owned > 0) H_TRY(sph_set_numbers_dev(h->c, 0, h->n_owned, h->gid.as<int64_t>()));
         H_TRY(sph_density(h->c));
-        if (multi) if (int st = refresh_start(h, 1, RHO)) return st;
+        if (multi) if (int st = refresh_start(h, h->variable ? 2 : 1, RHO)) return st;      // variable h: rho and Omega
     } else {
         // the density sum needs positions and masses only: it runs while the ghosts' v, u, alpha travel
         if (multi && h->vel_dirty) if (int st = refresh_start(h, 5, VEL)) return st;
         H_TRY(sph_density(h->c));
     }
     h->pos_dirty = h->vel_dirty = false;
-    if (multi) {
+    if (multi && !h->octree) {
         // ... and so do the forces of the wavefronts that cannot see a ghost
         H_TRY(sph_forces_part(h->c, 1));
         if (int st = refresh_finish(h)) return st;
         H_TRY(sph_refresh_eos_ghosts(h->c));
         H_TRY(sph_forces_part(h->c, 2));
+    } else if (multi) {
+        // the octree paths evaluate in one piece (the tree walk and the grad-h pass have no interior / boundary split)
+        if (int st = refresh_finish(h)) return st;
+        H_TRY(sph_refresh_eos_ghosts(h->c));
+        H_TRY(sph_forces(h->c));
     } else {
         H_TRY(sph_forces(h->c));
     }
     return reduce_start(h, before_drift);
+}
+
+// survivors of an accretion / cull keep their global numbers (the reference's pack(), [F]:481,554, applied to this object's list)
+int compact_gid(sph_halo *h, int64_t n_before, int64_t n_after) {
+    if (n_after == n_before) return SPH_OK;
+    H_HIP(h->gid_new.need((size_t)std::max<int64_t>(n_after, 1) * 8));
+    H_HIP(h->sel_count.need(8));
+    size_t tmp_bytes = 0;
+    H_HIP(rocprim::select(nullptr, tmp_bytes, h->gid.as<int64_t>(), h->keep.as<int32_t>(), h->gid_new.as<int64_t>(), h->sel_count.as<size_t>(),
+                          (size_t)n_before, h->s0));
+    H_HIP(h->sel_tmp.need(tmp_bytes));
+    H_HIP(rocprim::select(h->sel_tmp.p, tmp_bytes, h->gid.as<int64_t>(), h->keep.as<int32_t>(), h->gid_new.as<int64_t>(), h->sel_count.as<size_t>(),
+                          (size_t)n_before, h->s0));
+    std::swap(h->gid, h->gid_new);
+    return SPH_OK;
+}
+
+// initiate_sink_accretion + check_bounds, [F]:919-920 ([V]:1156-1158).  Several ranks: every rank decides for its own particles
+// on the shared octree; the per-sink sums over the accreted particles are all-gathered and added in rank order, so every rank
+// updates the (replicated) sinks identically (dist.py _accrete_and_cull).  One rank: the context's own pass.
+int accrete_and_cull(sph_halo *h) {
+    const int P = h->P;
+    const int64_t n_before = h->n_owned;
+    int64_t removed = 0;
+    H_HIP(h->keep.need((size_t)std::max<int64_t>(n_before, 1) * 4));
+    if (P == 1) {
+        H_TRY(sph_accrete_and_cull_keep(h->c, h->keep.as<int32_t>(), &removed));
+        if (removed > 0) h->pos_dirty = true;          // variable h: the survivors' numbers are set again before the next pass
+    } else {
+        int64_t off = 0;
+        for (int q = 0; q < h->rank; q++) off += h->counts_all[q];
+        H_HIP(h->accp.need(ACC_PARTIALS * 8));
+        H_HIP(h->accall.need((size_t)P * ACC_PARTIALS * 8));
+        H_TRY(sph_accrete_mark_dev(h->c, off, h->accp.as<double>()));
+        if (int st = s0_then_s1(h)) return st;
+        H_TR(h->tr->allgather(h->accp.p, h->accall.p, ACC_PARTIALS * 8, h->s1));
+        h->st.collectives++;
+        if (int st = s1_then_s0(h)) return st;
+        H_TRY(sph_accrete_apply_dev(h->c, h->accall.as<double>(), P, ACC_PARTIALS, h->keep.as<int32_t>(), &removed));
+        // the ghosts were dropped with the accreted particles: exchange before the next pass
+        h->pos_dirty = true; h->vel_dirty = false;
+        h->counts_valid = false; h->sources_valid = false;
+        for (int q = 0; q < P; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; }
+    }
+    if (removed > 0) {
+        if (int st = compact_gid(h, n_before, n_before - removed)) return st;
+        h->n_owned = n_before - removed;
+        h->pred_for_drift = false; h->pred_valid = false;
+    }
+    h->st.removed += removed;
+    return SPH_OK;
+}
+
+// check_sink_creation, [V]:549-597: the first particle by global number that qualifies, found with one all-gather; every rank
+// adds the same sink (the sinks are replicated)
+int create_sink(sph_halo *h) {
+    int32_t created = 0;
+    if (h->P == 1) {
+        H_TRY(sph_check_sink_creation(h->c, &created));
+    } else {
+        H_HIP(h->cand.need(9 * 8));
+        H_HIP(h->candall.need((size_t)h->P * 9 * 8));
+        H_TRY(sph_sink_candidate_dev(h->c, h->cand.as<double>()));
+        if (int st = s0_then_s1(h)) return st;
+        H_TR(h->tr->allgather(h->cand.p, h->candall.p, 9 * 8, h->s1));
+        h->st.collectives++;
+        if (int st = s1_then_s0(h)) return st;
+        pick_candidate<<<1, 64, 0, h->s0>>>(h->candall.as<double>(), h->P, h->cand.as<double>());
+        H_HIP(hipGetLastError());
+        H_TRY(sph_add_sink_checked_dev(h->c, h->cand.as<double>(), &created));
+    }
+    h->st.sinks_created += created;
+    return SPH_OK;
 }
 
 int step(sph_halo *h) {
@@ -694,6 +921,7 @@ int step(sph_halo *h) {
     if (int st = reduce_finish(h, true)) return st;       // the kick needs the new dt: nothing to put in between
     H_TRY(sph_kick_drift_devdt(h->c));
     h->pos_dirty = true;
+    h->sources_valid = false;
     h->pred_for_drift = true;                   // the reduction above predicted where this drift takes everybody
     h->since_migrate++;
     if (int st = evaluate(h, false)) return st;           // a kick follows, no drift
@@ -704,6 +932,12 @@ int step(sph_halo *h) {
     H_TRY(sph_kick_sinks_devdt(h->c));
     h->vel_dirty = true;
     h->dt_pending = true;
+    if (h->variable) {
+        H_TRY(sph_update_h(h->c));              // calc_smoothing, [V]:1152; the ghosts' h is stale now: full exchange next
+        if (h->P > 1) { h->pos_dirty = true; h->vel_dirty = false; }
+    }
+    if (h->sink_creation) if (int st = create_sink(h)) return st;                 // [V]:1155
+    if (h->accrete) if (int st = accrete_and_cull(h)) return st;                  // [F]:919-920
     return SPH_OK;
 }
 
@@ -738,7 +972,8 @@ void destroy_impl(sph_halo *h) {
     if (h->c && h->s0) (void)sph_set_stream(h->c, nullptr);     // the context outlives this object: off our stream before it goes
     delete h->tr;
     for (DevBuf *b : {&h->gid, &h->gid_new, &h->own, &h->newbuf, &h->part, &h->allpart, &h->row, &h->box, &h->boxes, &h->cnt, &h->cntall,
-                      &h->ghosts, &h->dest, &h->flags, &h->keep_ids, &h->sel_tmp, &h->sel_count}) b->release();
+                      &h->ghosts, &h->dest, &h->flags, &h->keep_ids, &h->sel_tmp, &h->sel_count, &h->src, &h->srcmine, &h->srcall, &h->accp,
+                      &h->accall, &h->keep, &h->cand, &h->candall, &h->gnum}) b->release();
     for (int q = 0; q < MAXP; q++) { h->sendb[q].release(); h->recvb[q].release(); h->ids[q].release(); }
     if (h->pin) (void)hipHostFree(h->pin);
     for (hipEvent_t e : {h->e01, h->e10, h->e_pred}) if (e) (void)hipEventDestroy(e);
@@ -845,12 +1080,13 @@ int sph_halo_set_slabs(sph_halo *h, const double *edges, int32_t migrate_every) 
     return SPH_OK;
 }
 
-int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, const double *z, const double *vx, const double *vy,
-                    const double *vz, const double *u, const double *m, const double *alpha, const int64_t *gid) {
+static int upload_impl(sph_halo *h, int64_t n, const double *const st9[9], const double *hsml, const int64_t *gid) {
     if (!h || n < 0) return SPH_ERR_ARG;
+    if (h->variable && n > 0 && !hsml) { h->err = "sph_halo_upload: a variable-h context needs the smoothing lengths (sph_halo_upload_v)"; return SPH_ERR_ARG; }
     DevGuard g(h->device);
     if (int st = ensure_reserve(h, n)) return st;
-    H_TRY(sph_upload(h->c, n, x, y, z, vx, vy, vz, u, m, alpha));
+    H_TRY(sph_upload(h->c, n, st9[0], st9[1], st9[2], st9[3], st9[4], st9[5], st9[6], st9[7], st9[8]));
+    if (h->variable && n > 0) H_TRY(sph_upload_field(h->c, SPH_F_H, hsml, n));
     H_HIP(h->gid.need((size_t)std::max<int64_t>(n, 1) * 8));
     if (n > 0) {
         if (gid) H_HIP(hipMemcpyAsync(h->gid.p, gid, (size_t)n * 8, hipMemcpyHostToDevice, h->s0));
@@ -860,9 +1096,22 @@ int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, co
     h->n_owned = n;
     h->uploaded = true;
     h->pos_dirty = true; h->vel_dirty = false; h->dt_pending = false; h->pred_for_drift = false; h->pred_valid = false;
+    h->counts_valid = false; h->sources_valid = false;
     h->since_migrate = 0;
     for (int q = 0; q < MAXP; q++) { h->send_count[q] = 0; h->ghost_count[q] = 0; h->cap_send[q] = 0; h->cap_recv[q] = 0; }
     return SPH_OK;
+}
+
+int sph_halo_upload(sph_halo *h, int64_t n, const double *x, const double *y, const double *z, const double *vx, const double *vy,
+                    const double *vz, const double *u, const double *m, const double *alpha, const int64_t *gid) {
+    const double *st9[9] = {x, y, z, vx, vy, vz, u, m, alpha};
+    return upload_impl(h, n, st9, nullptr, gid);
+}
+
+int sph_halo_upload_v(sph_halo *h, int64_t n, const double *x, const double *y, const double *z, const double *vx, const double *vy,
+                      const double *vz, const double *u, const double *m, const double *alpha, const double *hsml, const int64_t *gid) {
+    const double *st9[9] = {x, y, z, vx, vy, vz, u, m, alpha};
+    return upload_impl(h, n, st9, hsml, gid);
 }
 
 int sph_halo_run(sph_halo *h, int32_t nsteps, double *dt, double *t) {
@@ -878,15 +1127,14 @@ int sph_halo_run(sph_halo *h, int32_t nsteps, double *dt, double *t) {
 
 int64_t sph_halo_count(const sph_halo *h) { return h ? h->n_owned : -1; }
 
-int sph_halo_download(sph_halo *h, int64_t capacity, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *u,
-                      double *m, double *alpha, int64_t *gid) {
+static int download_impl(sph_halo *h, int64_t capacity, double *const dst[NF_MAX], int64_t *gid) {
     if (!h || capacity < h->n_owned) return SPH_ERR_ARG;
     DevGuard g(h->device);
+    const int NF = h->nf;
     const int64_t n = h->n_owned;
     if (n == 0) return SPH_OK;
     H_HIP(h->own.need((size_t)n * NF * 8));
     H_TRY(sph_gather_fields_dev(h->c, NF, STATE, n, nullptr, h->own.as<double>()));
-    double *dst[NF] = {x, y, z, vx, vy, vz, u, m, alpha};
     for (int f = 0; f < NF; f++)
         if (dst[f]) H_HIP(hipMemcpyAsync(dst[f], h->own.as<double>() + (size_t)f * n, (size_t)n * 8, hipMemcpyDeviceToHost, h->s0));
     if (gid) H_HIP(hipMemcpyAsync(gid, h->gid.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->s0));
@@ -894,11 +1142,23 @@ int sph_halo_download(sph_halo *h, int64_t capacity, double *x, double *y, doubl
     return SPH_OK;
 }
 
-int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z, double *vx,
-                         double *vy, double *vz, double *u, double *m, double *alpha, int64_t *gid) {
+int sph_halo_download(sph_halo *h, int64_t capacity, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *u,
+                      double *m, double *alpha, int64_t *gid) {
+    double *dst[NF_MAX] = {x, y, z, vx, vy, vz, u, m, alpha, nullptr};
+    return download_impl(h, capacity, dst, gid);
+}
+
+int sph_halo_download_v(sph_halo *h, int64_t capacity, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *u,
+                        double *m, double *alpha, double *hsml, int64_t *gid) {
+    if (h && !h->variable && hsml) { h->err = "sph_halo_download_v: the context has no per-particle h"; return SPH_ERR_ARG; }
+    double *dst[NF_MAX] = {x, y, z, vx, vy, vz, u, m, alpha, hsml};
+    return download_impl(h, capacity, dst, gid);
+}
+
+static int gather_root_impl(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *const dst[NF_MAX], int64_t *gid) {
     if (!h || root < 0 || root >= h->P || !n_total) return SPH_ERR_ARG;
     DevGuard g(h->device);
-    const int P = h->P;
+    const int P = h->P, NF = h->nf;
     const int64_t n = h->n_owned;
     int64_t mine[MAXP];
     for (int q = 0; q < P; q++) mine[q] = q == root ? n : 0;       // row r of the matrix: what rank r sends to each rank
@@ -909,7 +1169,7 @@ int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n
     *n_total = total;
     const bool is_root = h->rank == root;
     const bool fits = !is_root || capacity >= total;
-    // payload: the 9 state rows + the global number
+    // payload: the state rows + the global number
     H_HIP(h->own.need((size_t)std::max<int64_t>(n, 1) * (NF + 1) * 8));
     if (n > 0) {
         H_TRY(sph_gather_fields_dev(h->c, NF, STATE, n, nullptr, h->own.as<double>()));
@@ -949,11 +1209,22 @@ int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n
     std::iota(order.begin(), order.end(), (int64_t)0);
     const double *gd = &all[(size_t)NF * total];
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gd[a] < gd[b]; });
-    double *dst[NF] = {x, y, z, vx, vy, vz, u, m, alpha};
     for (int f = 0; f < NF; f++)
         if (dst[f]) for (int64_t k = 0; k < total; k++) dst[f][k] = all[(size_t)f * total + order[(size_t)k]];
     if (gid) for (int64_t k = 0; k < total; k++) gid[k] = (int64_t)gd[order[(size_t)k]];
     return SPH_OK;
+}
+
+int sph_halo_gather_root(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z, double *vx,
+                         double *vy, double *vz, double *u, double *m, double *alpha, int64_t *gid) {
+    double *dst[NF_MAX] = {x, y, z, vx, vy, vz, u, m, alpha, nullptr};
+    return gather_root_impl(h, root, capacity, n_total, dst, gid);
+}
+
+int sph_halo_gather_root_v(sph_halo *h, int32_t root, int64_t capacity, int64_t *n_total, double *x, double *y, double *z, double *vx,
+                           double *vy, double *vz, double *u, double *m, double *alpha, double *hsml, int64_t *gid) {
+    double *dst[NF_MAX] = {x, y, z, vx, vy, vz, u, m, alpha, hsml};
+    return gather_root_impl(h, root, capacity, n_total, dst, gid);
 }
 
 int sph_halo_get_stats(const sph_halo *h, sph_halo_stats *out) {

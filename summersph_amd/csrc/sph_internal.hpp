@@ -263,7 +263,7 @@ int global_keys_sorted(sph_ctx *c);      // sorted path keys of the external sou
 void gravity_free(sph_ctx *c);
 hipError_t launch_gravity(sph_ctx *c);
 // accretion + boundary cull (accrete.hip)
-int accrete_and_cull(sph_ctx *c, int64_t *removed);
+int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out = nullptr);
 int sink_creation(sph_ctx *c, int32_t *created);
 int sink_candidate(sph_ctx *c, double *d_cand);    // multi-GPU halves of sink_creation
 int sink_add_checked(sph_ctx *c, const double *d_cand, int32_t *created);

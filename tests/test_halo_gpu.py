@@ -340,7 +340,8 @@ def test_bench_glue_of_the_native_loop_one_rank():
     rows = ic.keplerian_disc(20000, seed=43)
     gas, sinks = ic.split_rows(rows)
     mine = dict(gas); mine["gid"] = np.arange(gas["x"].size)
-    sim = bench.NativeSim.create(capi, OneRank, torch, 0, 0, 1, 0, mine, sinks, np.zeros(0))
+    env = {"capi": capi, "dist": OneRank, "torch": torch, "rank": 0, "world": 1, "local_rank": 0}
+    sim = bench.NativeSim.create(env, 0, mine, sinks, np.zeros(0))
     assert sim is not None
     dt = sim.run(3, 1e-2)
     dt = sim.run(4, dt)
