@@ -326,7 +326,7 @@ class NativeSim:
     """bench face of the native multi-GPU step loop (summersph_amd/halo.py): what DistSim offers the timed region"""
 
     @classmethod
-    def create(cls, env, flags, mine, sinks, bounds):
+    def create(cls, env, flags, mine, sinks, bounds, variable=False):
         from summersph_amd import halo
         capi, dist, torch, rank, world = env["capi"], env["dist"], env["torch"], env["rank"], env["world"]
         uid = [halo.unique_id() if rank == 0 else None]
@@ -340,7 +340,8 @@ class NativeSim:
 
         ok = True
         try:
-            self.ctx = capi.Context(device=env["local_rank"], flags=flags)
+            self.ctx = (capi.Context(device=env["local_rank"], variable=True, flags=flags | capi.FLAG_VARIABLE_H) if variable
+                        else capi.Context(device=env["local_rank"], flags=flags))
             self.h = halo.Halo.rccl(self.ctx, uid[0], rank, world)
         except Exception as e:       # noqa: BLE001 -- e.g. two ranks on one GPU: RCCL refuses
             ok = False
@@ -371,7 +372,8 @@ class NativeSim:
     @property
     def stats(self):
         s = self.h.stats()
-        return {"ghosts": s.ghosts, "migrated": s.migrated, "exchanges": s.exchanges, "migrations": s.migrations, "host_waits": s.host_waits}
+        return {"ghosts": s.ghosts, "migrated": s.migrated, "exchanges": s.exchanges, "collectives": s.collectives, "migrations": s.migrations,
+                "host_waits": s.host_waits, "removed": s.removed, "sinks_created": s.sinks_created}
 
     def close(self):
         self.h.close(); self.ctx.close()
@@ -383,8 +385,9 @@ PLANES = {"nccl": "RCCL (summersph_amd/dist.py over torch.distributed nccl)",
 
 
 def native_applies(variable, flags, capi):
-    """what libsummersph_halo.so's step loop covers (include/summersph_halo.h)"""
-    return not variable and not (flags & (capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL))
+    """what libsummersph_halo.so's step loop covers (include/summersph_halo.h): every flavour of the loop body; accretion on
+    several ranks needs the shared octree, i.e. self-gravity or variable h (as in the reference, which always has gravity)"""
+    return variable or bool(flags & capi.FLAG_SELF_GRAVITY) or not (flags & capi.FLAG_ACCRETE_CULL)
 
 
 def dist_run(env, rows, variable, flags, steps, warmup, halo_mode, dominant=("forces",), profile=False):
@@ -402,7 +405,7 @@ def dist_run(env, rows, variable, flags, steps, warmup, halo_mode, dominant=("fo
     del gas
     plane, sim = env["data_backend"], None
     if halo_mode in ("auto", "native") and plane == "nccl" and native_applies(variable, flags, capi):
-        sim = NativeSim.create(env, flags, mine, sinks, bounds)
+        sim = NativeSim.create(env, flags, mine, sinks, bounds, variable)
         if sim is None and rank == 0:
             print("[bench] native halo unavailable on some rank; using dist.py", file=sys.stderr, flush=True)
         if sim is not None:
@@ -501,7 +504,17 @@ def main():
         # ranks given the same GPU), every rank falls back to host-staged gloo messages and the JSON line says so.
         local_rank = local_rank % max(torch.cuda.device_count(), 1)      # fewer GPUs than ranks: share (RCCL refuses, gloo runs)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo")
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
         if args.backend == "nccl":
             ok = 1
             try:

@@ -29,7 +29,7 @@ FLAG_NO_REFLAG = 512
 
 # every symbol include/summersph.h declares (tests check that the library exports them all)
 SYMBOLS = [
-    "sph_set_sink_radii", "sph_accrete_and_cull",
+    "sph_set_sink_radii", "sph_accrete_and_cull", "sph_accrete_and_cull_keep",
     "sph_params_default", "sph_params_default_variable", "sph_upload_field", "sph_upload_field_dev", "sph_update_h",
     "sph_ctx_create", "sph_ctx_destroy", "sph_strerror", "sph_last_error", "sph_abi_version", "sph_get_params",
     "sph_upload", "sph_upload_dev", "sph_set_sinks", "sph_get_sinks", "sph_count", "sph_sink_count", "sph_check_sink_creation", "sph_get_sink_radii", "sph_sink_candidate_dev", "sph_add_sink_checked_dev",

@@ -21,6 +21,7 @@ SYMBOLS = [
     "sph_halo_unique_id", "sph_halo_create", "sph_halo_attach", "sph_halo_hub_create", "sph_halo_hub_destroy",
     "sph_halo_create_inproc", "sph_halo_destroy", "sph_halo_last_error", "sph_halo_set_slabs", "sph_halo_upload",
     "sph_halo_run", "sph_halo_count", "sph_halo_download", "sph_halo_gather_root", "sph_halo_get_stats", "sph_halo_selftest",
+    "sph_halo_upload_v", "sph_halo_download_v", "sph_halo_gather_root_v",
 ]
 STATE = "x y z vx vy vz u m alpha".split()
 _D = C.POINTER(C.c_double)
@@ -28,7 +29,7 @@ _lib = None
 
 
 class HaloStats(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in "ghosts migrated exchanges collectives migrations host_waits".split()]
+    _fields_ = [(k, C.c_int64) for k in "ghosts migrated exchanges collectives migrations host_waits removed sinks_created".split()]
 
 
 def load():
@@ -66,6 +67,9 @@ def load():
     lib.sph_halo_run.argtypes = [C.c_void_p, C.c_int32, _D, _D]
     lib.sph_halo_download.argtypes = [C.c_void_p, C.c_int64] + [_D] * 9 + [C.POINTER(C.c_int64)]
     lib.sph_halo_gather_root.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64)] + [_D] * 9 + [C.POINTER(C.c_int64)]
+    lib.sph_halo_upload_v.argtypes = [C.c_void_p, C.c_int64] + [_D] * 10 + [C.POINTER(C.c_int64)]
+    lib.sph_halo_download_v.argtypes = [C.c_void_p, C.c_int64] + [_D] * 10 + [C.POINTER(C.c_int64)]
+    lib.sph_halo_gather_root_v.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64)] + [_D] * 10 + [C.POINTER(C.c_int64)]
     lib.sph_halo_get_stats.argtypes = [C.c_void_p, C.POINTER(HaloStats)]
     lib.sph_halo_selftest.argtypes = [C.c_void_p, C.c_int64]
     _lib = lib
@@ -143,14 +147,23 @@ class Halo:
         assert e.size == self.nranks - 1
         self._ck(self.lib.sph_halo_set_slabs(self._h, _dp(e) if e.size else None, int(migrate_every)))
 
+    @property
+    def variable(self) -> bool:
+        return bool(self.ctx.params.flags & capi.FLAG_VARIABLE_H)
+
     def upload(self, gas: dict):
+        """this rank's particles; a variable-h context also takes gas["h"] (the 10th column of [V]'s reader)"""
         arrs = [np.ascontiguousarray(gas[k], dtype=np.float64) for k in STATE[:8]]
         al = gas.get("alpha")
         al = None if al is None else np.ascontiguousarray(al, dtype=np.float64)
         gid = gas.get("gid")
         gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.int64)
-        self._ck(self.lib.sph_halo_upload(self._h, arrs[0].size, *[_dp(a) for a in arrs], _dp(al),
-                                          gid.ctypes.data_as(C.POINTER(C.c_int64)) if gid is not None else None))
+        gp = gid.ctypes.data_as(C.POINTER(C.c_int64)) if gid is not None else None
+        if self.variable:
+            hs = np.ascontiguousarray(gas["h"], dtype=np.float64)
+            self._ck(self.lib.sph_halo_upload_v(self._h, arrs[0].size, *[_dp(a) for a in arrs], _dp(al), _dp(hs), gp))
+        else:
+            self._ck(self.lib.sph_halo_upload(self._h, arrs[0].size, *[_dp(a) for a in arrs], _dp(al), gp))
 
     def run(self, nsteps: int, dt: float, t: float = 0.0):
         d, tt = C.c_double(dt), C.c_double(t)
@@ -163,20 +176,23 @@ class Halo:
 
     def download(self) -> dict:
         n = self.n_owned
-        out = {k: np.empty(n) for k in STATE}
+        names = STATE + (["h"] if self.variable else [])
+        out = {k: np.empty(n) for k in names}
         gid = np.empty(n, dtype=np.int64)
-        self._ck(self.lib.sph_halo_download(self._h, n, *[_dp(out[k]) for k in STATE], gid.ctypes.data_as(C.POINTER(C.c_int64))))
+        fn = self.lib.sph_halo_download_v if self.variable else self.lib.sph_halo_download
+        self._ck(fn(self._h, n, *[_dp(out[k]) for k in names], gid.ctypes.data_as(C.POINTER(C.c_int64))))
         out["gid"] = gid
         return out
 
     def gather_root(self, root: int, capacity: int):
         """collective; on `root` a dict of the whole particle set in global-number order, elsewhere None"""
         cap = int(capacity) if self.rank == root else 0
-        out = {k: np.empty(cap) for k in STATE}
+        names = STATE + (["h"] if self.variable else [])
+        out = {k: np.empty(cap) for k in names}
         gid = np.empty(cap, dtype=np.int64)
         nt = C.c_int64()
-        self._ck(self.lib.sph_halo_gather_root(self._h, int(root), cap, C.byref(nt), *[_dp(out[k]) for k in STATE],
-                                               gid.ctypes.data_as(C.POINTER(C.c_int64))))
+        fn = self.lib.sph_halo_gather_root_v if self.variable else self.lib.sph_halo_gather_root
+        self._ck(fn(self._h, int(root), cap, C.byref(nt), *[_dp(out[k]) for k in names], gid.ctypes.data_as(C.POINTER(C.c_int64))))
         if self.rank != root:
             return None
         res = {k: v[:nt.value] for k, v in out.items()}

@@ -1,18 +1,20 @@
 ! run_sph_hip_mg.f90 -- the Fortran host on several GPUs: one process per GPU, no Python, no MPI.
 !
-!   run_sph_hip_mg <rank> <nranks> <id_file> <ic.txt> <max_steps> [final_snapshot.txt] [saves] [tend=<end time>] [device=<d>]
+!   run_sph_hip_mg <rank> <nranks> <id_file> <ic.txt> <max_steps> [final_snapshot.txt] [sph] [saves] [tend=<end time>] [device=<d>]
 !
 ! Every rank reads the same input file (read_data_from_file, [F]:594-716), keeps the particles of its slab along x (equal
-! counts) and runs the SPH loop body ([F]:889-916, the "sph" mode of run_sph_hip: no gas self-gravity, accretion or cull)
-! through libsummersph_halo.so.  Rank 0 creates the RCCL id and writes it to <id_file> (which must not exist before);
+! counts) and runs the loop body of simulate ([F]:889-920) through libsummersph_halo.so -- as run_sph_hip does on one GPU: with
+! the Barnes-Hut gas self-gravity of find_forces (on the replicated tree of the all-gathered particles), sink accretion and the
+! boundary cull by default, without them with "sph".  Rank 0 creates the RCCL id and writes it to <id_file> (which must not exist before);
 ! the other ranks wait for that file: any shared directory serves, run_mg.sh starts the ranks of one node.
-! Snapshots are gathered on rank 0 in the input order, so the files are those of run_sph_hip ... sph.
-! Status: never run on more than one GPU (the test pool has single-GPU boxes); with nranks = 1 it is run_sph_hip ... sph.
+! Snapshots are gathered on rank 0 in the input order, so the files are those of run_sph_hip.
+! Status: never run on more than one GPU (the test pool has single-GPU boxes); with nranks = 1 it writes, byte for byte, what
+! run_sph_hip writes (tests/test_halo_gpu.py).
 program run_sph_hip_mg
   use, intrinsic :: iso_c_binding
   use sph_hip_binding
   use sph_hip_halo_binding
-  use sph_hip_host, only: dp, particle, sink, read_data_from_file, make_save, smoothing
+  use sph_hip_host, only: dp, particle, sink, read_data_from_file, make_save, smoothing, bounding_size
   implicit none
   character(len=512) :: id_file, filename, arg, snapshot
   type(particle), allocatable :: bodies(:), whole(:)
@@ -23,7 +25,7 @@ program run_sph_hip_mg
   integer(c_int8_t) :: id(SPH_HALO_ID_BYTES)
   integer :: rank, nranks, nsteps, dev, k, n, nmine, step, save_no, io, ios, tries
   integer(c_int64_t) :: n_total
-  logical :: with_saves, there
+  logical :: with_saves, there, only_sph
   real(dp) :: tend, next_save
   real(c_double) :: dt, t
   real(c_double), allocatable :: xs(:), edges(:), a(:, :), s(:, :), w(:, :)
@@ -33,7 +35,7 @@ program run_sph_hip_mg
   ctx = c_null_ptr
   halo = c_null_ptr
   if (command_argument_count() < 5) then
-    write(*, *) 'usage: run_sph_hip_mg <rank> <nranks> <id_file> <ic.txt> <max_steps> [snapshot] [saves] [tend=..] [device=..]'
+    write(*, *) 'usage: run_sph_hip_mg <rank> <nranks> <id_file> <ic.txt> <max_steps> [snapshot] [sph] [saves] [tend=..] [device=..]'
     error stop 2
   end if
   call get_command_argument(1, arg); read(arg, *) rank
@@ -43,12 +45,15 @@ program run_sph_hip_mg
   call get_command_argument(5, arg); read(arg, *) nsteps
   snapshot = ''
   with_saves = .false.
+  only_sph = .false.
   tend = 1000.0_dp
   dev = rank
   do k = 6, command_argument_count()
     call get_command_argument(k, arg)
     if (trim(arg) == 'saves') then
       with_saves = .true.
+    else if (trim(arg) == 'sph') then
+      only_sph = .true.
     else if (arg(1:5) == 'tend=') then
       read(arg(6:), *) tend
     else if (arg(1:7) == 'device=') then
@@ -77,7 +82,10 @@ program run_sph_hip_mg
 
   call check(sph_params_default(prm), 'sph_params_default')
   prm%h = smoothing
-  prm%flags = 0
+  ! find_forces as it is (with the gas self-gravity term) + end-of-step accretion and cull, [F]:825,919-920
+  prm%flags = ior(SPH_FLAG_SELF_GRAVITY, SPH_FLAG_ACCRETE_CULL)
+  if (only_sph) prm%flags = 0
+  prm%bounding_size = bounding_size
   call check(sph_ctx_create(prm, int(dev, c_int), ctx), 'sph_ctx_create')
 
   ! the communicator id: rank 0 makes it, the file carries it
@@ -141,7 +149,7 @@ program run_sph_hip_mg
     if (with_saves) then
       if (save_no == 0 .or. t > next_save) then       ! the reference's cadence, as in sph_hip_host
         call collect()
-        if (rank == 0) call make_save(whole, sinks, save_no)
+        if (rank == 0) call make_save(whole(1:int(n_total)), sinks, save_no)
         save_no = save_no + 1
         next_save = (save_no * tend) / 1000
       end if
@@ -152,11 +160,11 @@ program run_sph_hip_mg
   end do
   if (len_trim(snapshot) > 0) then
     call collect()
-    if (rank == 0) call make_save(whole, sinks, 0, trim(snapshot))
+    if (rank == 0) call make_save(whole(1:int(n_total)), sinks, 0, trim(snapshot))
   end if
   call check(sph_halo_get_stats(halo, hs), 'sph_halo_get_stats')
-  write(*, '(A,I0,A,I0,A,I0,A,I0,A,I0)') 'rank ', rank, ': owned ', sph_halo_count(halo), ' ghosts ', hs%ghosts, &
-    ' migrated(all ranks) ', hs%migrated, ' exchanges ', hs%exchanges
+  write(*, '(A,I0,A,I0,A,I0,A,I0,A,I0,A,I0)') 'rank ', rank, ': owned ', sph_halo_count(halo), ' ghosts ', hs%ghosts, &
+    ' migrated(all ranks) ', hs%migrated, ' exchanges ', hs%exchanges, ' accreted+culled ', hs%removed
   call check(sph_halo_destroy(halo), 'sph_halo_destroy')
   call check(sph_ctx_destroy(ctx), 'sph_ctx_destroy')
 

@@ -13,7 +13,7 @@ module sph_hip_halo_binding
   integer, parameter :: SPH_HALO_ID_BYTES = 128
 
   type, bind(C) :: sph_halo_stats
-    integer(c_int64_t) :: ghosts, migrated, exchanges, collectives, migrations, host_waits
+    integer(c_int64_t) :: ghosts, migrated, exchanges, collectives, migrations, host_waits, removed, sinks_created
   end type sph_halo_stats
 
   interface
@@ -84,6 +84,35 @@ module sph_hip_halo_binding
       integer(c_int64_t), value :: capacity
       integer(c_int64_t), intent(out) :: n_total
       real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), u(*), m(*), alpha(*)
+      integer(c_int64_t), intent(out) :: gid(*)
+    end function
+
+    ! variable-h contexts ("SUMMER_SPH - Variable.f90"): the same three with the smoothing lengths as a 10th array
+    integer(c_int) function sph_halo_upload_v(halo, n, x, y, z, vx, vy, vz, u, m, alpha, hsml, gid) bind(C, name='sph_halo_upload_v')
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: halo
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), u(*), m(*), alpha(*), hsml(*)
+      integer(c_int64_t), intent(in) :: gid(*)
+    end function
+
+    integer(c_int) function sph_halo_download_v(halo, capacity, x, y, z, vx, vy, vz, u, m, alpha, hsml, gid) &
+        bind(C, name='sph_halo_download_v')
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: halo
+      integer(c_int64_t), value :: capacity
+      real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), u(*), m(*), alpha(*), hsml(*)
+      integer(c_int64_t), intent(out) :: gid(*)
+    end function
+
+    integer(c_int) function sph_halo_gather_root_v(halo, root, capacity, n_total, x, y, z, vx, vy, vz, u, m, alpha, hsml, gid) &
+        bind(C, name='sph_halo_gather_root_v')
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: halo
+      integer(c_int32_t), value :: root
+      integer(c_int64_t), value :: capacity
+      integer(c_int64_t), intent(out) :: n_total
+      real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), u(*), m(*), alpha(*), hsml(*)
       integer(c_int64_t), intent(out) :: gid(*)
     end function
 

@@ -296,7 +296,7 @@ def test_fortran_multi_gpu_host_one_rank(tmp_path):
     a = subprocess.run([os.path.join(host, "run_sph_hip"), str(icf), "5", str(tmp_path / "one.txt"), "sph"],
                        capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert a.returncode == 0, a.stdout + a.stderr
-    b = subprocess.run([os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id.bin"), str(icf), "5", str(tmp_path / "mg.txt")],
+    b = subprocess.run([os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id.bin"), str(icf), "5", str(tmp_path / "mg.txt"), "sph"],
                        capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert b.returncode == 0, b.stdout + b.stderr
     dts = lambda out: [l for l in out.splitlines() if l.startswith("dt ")]
@@ -306,7 +306,7 @@ def test_fortran_multi_gpu_host_one_rank(tmp_path):
     # the periodic saves through the collective gather: the same files as the single-GPU host writes
     for sub, cmd in (("s1", [os.path.join(host, "run_sph_hip"), str(icf), "4", str(tmp_path / "s1" / "f.txt"), "sph", "saves", "tend=20"]),
                      ("s2", [os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id2.bin"), str(icf), "4",
-                             str(tmp_path / "s2" / "f.txt"), "saves", "tend=20"])):
+                             str(tmp_path / "s2" / "f.txt"), "sph", "saves", "tend=20"])):
         (tmp_path / sub).mkdir()
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path / sub, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -314,6 +314,33 @@ def test_fortran_multi_gpu_host_one_rank(tmp_path):
     assert len(names) >= 2 and names == sorted(p.name for p in (tmp_path / "s2").glob("save*.txt"))
     for nm in names:
         assert (tmp_path / "s1" / nm).read_bytes() == (tmp_path / "s2" / nm).read_bytes(), nm
+
+
+def test_fortran_multi_gpu_host_one_rank_full_loop(tmp_path):
+    """run_sph_hip_mg WITHOUT `sph` = simulate() as the reference runs it (Barnes-Hut self-gravity, accretion, cull): with one
+    rank it writes what run_sph_hip writes, byte for byte, and both reproduce the real reference's dt decisions and particle
+    count (2000 -> 1996)"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from summersph_amd import txtio
+    host = os.path.join(ROOT, "summersph_amd", "host")
+    g = load_golden("acc2000_traj")
+    icf = tmp_path / "ic.txt"
+    txtio.write_ic(str(icf), g["ic"])
+    a = subprocess.run([os.path.join(host, "run_sph_hip"), str(icf), "3", str(tmp_path / "one.txt")],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([os.path.join(host, "run_sph_hip_mg"), "0", "1", str(tmp_path / "id.bin"), str(icf), "3", str(tmp_path / "mg.txt")],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    dts = lambda out: [l for l in out.splitlines() if l.startswith("dt ")]
+    assert dts(a.stdout) == dts(b.stdout)
+    assert [float(l.split()[2]) for l in dts(b.stdout)] == list(g["full_dt_seq"])
+    assert (tmp_path / "one.txt").read_bytes() == (tmp_path / "mg.txt").read_bytes()
+    gas, sinks = txtio.read_snapshot(str(tmp_path / "mg.txt"))
+    assert gas.shape[0] == int(g["full_n_seq"][-1]) == 1996
+    assert "accreted+culled 4" in b.stdout
 
 
 def test_bench_glue_of_the_native_loop_one_rank():
@@ -352,3 +379,162 @@ def test_bench_glue_of_the_native_loop_one_rank():
     assert dt == d2 and sim.t == t2
     assert np.array_equal(sim.h.download()["x"], ctx.field("x"))
     sim.h.close(); sim.ctx.close(); ctx.close()
+
+
+# ---- the loop the reference actually runs: self-gravity, accretion + cull, variable h, sink creation -----------------------
+
+def _run_ranks_ex(world, gas, sinks, nsteps, ctx_kw, migrate_every=2):
+    """as _run_ranks for any context flavour: per rank the dt sequence, owned counts per step, final state and sinks"""
+    hub = halo.Hub(world)
+    bounds = slab_bounds(gas["x"], world)
+    owner = np.searchsorted(bounds, gas["x"], side="right")
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = capi.Context(device=0, **ctx_kw)
+            h = halo.Halo.inproc(ctx, hub, rank, world)
+            sel = owner == rank
+            mine = {k: v[sel] for k, v in gas.items()}
+            mine["gid"] = np.nonzero(sel)[0]
+            ctx.set_sinks(sinks)
+            h.set_slabs(bounds, migrate_every)
+            h.upload(mine)
+            dts, ns, t = [1e-2], [], 0.0
+            for _ in range(nsteps):
+                dt, t = h.run(1, dts[-1], t)
+                dts.append(dt); ns.append(h.n_owned)
+            out[rank] = {"dts": dts, "ns": np.array(ns), "t": t, "state": h.download(), "stats": h.stats(), "sinks": ctx.get_sinks()}
+            h.close(); ctx.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the test below
+            errs.append((rank, repr(e)))
+            hub_fail.set()
+
+    hub_fail = threading.Event()
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    hub.close()
+    assert not errs, errs
+    return out
+
+
+def _merged(parts, f):
+    order = np.argsort(np.concatenate([p["state"]["gid"] for p in parts]))
+    return np.concatenate([p["state"][f] for p in parts])[order]
+
+
+def _var_kw(g, full):
+    gamma, eta, tol, maxlen, scale = (float(v) for v in g["params"])
+    kw = dict(variable=True, gamma=gamma, gamma_m1=gamma - 1.0, eta=eta, h_tol=tol, h_max_length=maxlen, dt_scale=scale)
+    if full:
+        kw["flags"] = capi.FLAG_VARIABLE_H | capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL | capi.FLAG_SINK_CREATION
+    return kw
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_loop_self_gravity_vs_reference(world):
+    """find_forces as the reference has it (Barnes-Hut term on the replicated tree of all-gathered sources) through the native
+    loop: the real reference's `full` trajectory of the 3000-particle disc"""
+    g = load_golden("disc3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks_ex(world, gas, sinks, 5, dict(flags=capi.FLAG_SELF_GRAVITY))
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert p["stats"].ghosts > 0
+    for f in FIELDS:
+        assert rel_err(_merged(parts, f), g["full_s5_" + f]) <= 1e-10, f
+
+
+@pytest.mark.parametrize("name,world", [("acc2000_traj", 2), ("acc2000_traj", 3), ("bin2000_traj", 2)])
+def test_native_loop_accretion_and_cull_vs_reference(name, world):
+    """simulate()'s whole loop body on several ranks: shared-tree gravity, accretion (one / two accretors), boundary cull --
+    identical dt decisions and particle counts, sinks and state against the real reference"""
+    g = load_golden(name)
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks_ex(world, gas, sinks, 3, dict(flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL))
+    assert list(sum(p["ns"] for p in parts)) == [int(v) for v in g["full_n_seq"][1:]]
+    gid = np.concatenate([p["state"]["gid"] for p in parts])
+    assert np.unique(gid).size == gid.size == int(g["full_n_seq"][-1])
+    assert sum(p["stats"].removed for p in parts) == int(g["full_n_seq"][0] - g["full_n_seq"][-1])
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert np.max(np.abs(p["sinks"]["m"] - g["full_s3_sm"])) <= 1e-15 and np.max(np.abs(p["sinks"]["x"] - g["full_s3_sx"])) <= 1e-12
+        assert np.array_equal(p["sinks"]["m"], parts[0]["sinks"]["m"])
+    for f in FIELDS:
+        assert rel_err(_merged(parts, f), g["full_s3_" + f]) <= 1e-10, f
+
+
+@pytest.mark.parametrize("variant,world", [("sph", 2), ("sph", 3), ("full", 2)])
+def test_native_loop_variable_h_vs_reference(variant, world):
+    """"SUMMER_SPH - Variable.f90" through the native loop: per-particle h and global numbers in the ghost payload, the leaf
+    boxes of the octree of all particles, rho AND Omega of the ghosts, calc_smoothing per rank; `full` adds self-gravity,
+    accretion and cull"""
+    g = load_golden("discv3000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks_ex(world, gas, sinks, 5, _var_kw(g, variant == "full"))
+    gid = np.concatenate([p["state"]["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(gid.size))
+    for p in parts:
+        assert list(p["dts"]) == list(g[variant + "_dt_seq"])
+        assert p["stats"].ghosts > 0
+    for f in FIELDS + ["h"]:
+        assert rel_err(_merged(parts, f), g[f"{variant}_s5_" + f]) <= 1e-10, f
+
+
+def test_native_loop_sink_creation_vs_reference():
+    """check_sink_creation on 2 ranks: the candidate with the lowest global number wins one all-gather, every rank adds the same
+    sink, which then accretes its seed"""
+    g = load_golden("sinkcv1500_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks_ex(2, gas, sinks, 3, _var_kw(g, True))
+    gid = np.concatenate([p["state"]["gid"] for p in parts])
+    assert gid.size == 1499
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert p["stats"].sinks_created == 1
+        assert p["sinks"]["m"].size == 2 and np.max(np.abs(p["sinks"]["m"] - g["full_s3_sm"]) / g["full_s3_sm"]) <= 1e-14
+        assert np.max(np.abs(p["sinks"]["x"] - g["full_s3_sx"])) <= 1e-9
+    for f in FIELDS + ["h"]:
+        assert rel_err(_merged(parts, f), g["full_s3_" + f]) <= 1e-9, f
+
+
+def test_native_loop_sink_cull_vs_reference():
+    """[V]'s check_bounds drops the sink that starts outside the box -- on every rank alike"""
+    g = load_golden("sinkcullv1000_traj")
+    gas, sinks = ic.split_rows(g["ic"])
+    parts = _run_ranks_ex(2, gas, sinks, 3, _var_kw(g, True))
+    for p in parts:
+        assert list(p["dts"]) == list(g["full_dt_seq"])
+        assert p["sinks"]["m"].size == 1 and p["sinks"]["m"][0] == g["full_s3_sm"][0]
+    for f in FIELDS + ["h"]:
+        assert rel_err(_merged(parts, f), g["full_s3_" + f]) <= 1e-10, f
+
+
+@pytest.mark.parametrize("flavour", ["full", "variable_full"])
+def test_native_loop_one_rank_is_sph_run_on_the_octree_paths(flavour):
+    """one rank, no messages: gravity, accretion + cull (and variable h with sink creation) through the native loop must give
+    what sph_run gives, bit for bit -- state, sinks, particle count, dt"""
+    if flavour == "full":
+        g = load_golden("acc2000_traj"); kw = dict(flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL); names = FIELDS
+    else:
+        g = load_golden("sinkcv1500_traj"); kw = _var_kw(g, True); names = FIELDS + ["h"]
+    gas, sinks = ic.split_rows(g["ic"])
+    one = _run_ranks_ex(1, gas, sinks, 3, kw)[0]
+    ctx = capi.Context(device=0, **kw)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    dt, t = 1e-2, 0.0
+    for _ in range(3):
+        dt, t = ctx.run(1, dt, t)
+    assert one["dts"][-1] == dt and one["t"] == t and one["state"]["x"].size == ctx.n
+    assert one["state"]["x"].size == int(g["full_n_seq"][-1])
+    for f in names:
+        assert np.array_equal(one["state"][f], ctx.field(f)), f
+    s = ctx.get_sinks()
+    for k in ("x", "vx", "m"):
+        assert np.array_equal(one["sinks"][k], s[k]), k
+    # the survivors kept their global numbers: exactly the particles the reference kept
+    assert np.all(np.diff(one["state"]["gid"]) > 0)
+    ctx.close()
