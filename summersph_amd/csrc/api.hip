@@ -77,8 +77,8 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     c->sort_tmp_bytes = tmp;
     API_TRY(ctx_alloc_bytes(c, &c->sort_tmp, tmp ? tmp : 1, "sort scratch"));
     c->nl_waves_cap = (cap + 63) / 64;
-    c->nl_cap = 96;   // grows on demand (nlist_build)
-    API_TRY(ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list"));
+    c->nl_cap = 96;   // grows on demand (nlist_build); the tiled fixed-h build writes 16-bit entries (tile_common.hpp)
+    API_TRY(ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * (c->tiled ? 32 : 64), "neighbour list"));
     API_TRY(ctx_alloc(c, &c->ncount, (size_t)cap, "neighbour counts"));
     API_TRY(ctx_alloc(c, &c->wave_max, (size_t)c->nl_waves_cap, "wave max"));
     API_TRY(ctx_alloc(c, &c->wave_class, (size_t)c->nl_waves_cap, "wave classes"));
@@ -169,6 +169,19 @@ void resolve_timing(sph_ctx *c) {
     }
 }
 
+// The whole-tile kernels are persistent, one workgroup per CU.  density_wt walks over groups of 1024 targets: with fewer groups
+// than CUs it leaves CUs idle, and below ~0.75 groups per CU the gather kernel of pairs.hip (a workgroup per 256 targets) is
+// faster -- measured on MI355X (tests/tools/small_n_ab.sh, ms per pass): 12 000 particles 0.032 vs 0.069, 100 000: 0.048 vs
+// 0.071, 300 000 (293 groups): 0.098 vs 0.077 for the tile kernel.  forces_q (groups of 256, four lanes per target) wins at every
+// size, 47 groups included (12 000 particles: 0.032 vs 0.049 ms).  SPH_TILE_MIN_GROUPS_D / _F: A/B switches (x0.01 groups per CU).
+bool use_tile_kernel(const sph_ctx *c, bool forces) {
+    static const int thr_d = getenv("SPH_TILE_MIN_GROUPS_D") ? atoi(getenv("SPH_TILE_MIN_GROUPS_D")) : 75;
+    static const int thr_f = getenv("SPH_TILE_MIN_GROUPS_F") ? atoi(getenv("SPH_TILE_MIN_GROUPS_F")) : 0;
+    if (!c->whole_tile || !(forces ? c->wt_ok_f : c->wt_ok)) return false;
+    const int64_t groups = (c->n + (forces ? 255 : 1023)) / (forces ? 256 : 1024);
+    return 100 * groups >= (int64_t)(forces ? thr_f : thr_d) * c->num_cus;
+}
+
 int do_density(sph_ctx *c) {
     static const bool no_refresh = getenv("SPH_NO_H_REFRESH") != nullptr;      // A/B switch
     if (!no_refresh && !c->grid_valid && c->variable && c->h_refresh_ok && c->order_valid && c->leaf_valid && c->n_slots == c->n) {
@@ -179,10 +192,20 @@ int do_density(sph_ctx *c) {
         API_TRY(varh_h_stats(c, c->h_new_is_build));
         c->h_new_is_build = false;
         { Timed t(c, SPH_K_LEAF); API_TRY(varh_refresh_h(c)); }
-        // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built
+        // the list of the new lengths: re-flagged from the list in place when no h outgrew its margin, else built.  The
+        // re-flag pass and the density pass that follows it walk the same rows: one kernel does both (SPH_NO_FUSED_REFLAG: A/B)
+        static const bool no_fused = getenv("SPH_NO_FUSED_REFLAG") != nullptr;
+        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
+        if (varh_can_reflag(c) && !no_fused) {
+            Timed t(c, SPH_K_REFLAG);
+            API_TRY(varh_reflag_density(c, make_pair_const(c)));
+            c->grid_valid = true; c->h_refresh_ok = false;
+            c->density_passes++;
+            c->rho_valid = true; c->eos_valid = true;
+            return SPH_OK;
+        }
         if (varh_can_reflag(c)) { Timed t(c, SPH_K_REFLAG); API_TRY(varh_nlist_reflag(c)); }
         else { Timed t(c, SPH_K_NLIST); API_TRY(varh_nlist_build(c)); }
-        c->rates_valid = false; c->rho_valid = false; c->eos_valid = false;
         c->grid_valid = true;
     }
     c->h_refresh_ok = false;
@@ -209,7 +232,7 @@ int do_density(sph_ctx *c) {
     if ((c->p.flags & SPH_FLAG_REUSE_DENSITY) && c->rho_valid) {
         API_HIP(c->variable ? launch_eos_only_v(c, pc) : launch_eos_only(c, pc));
     } else {
-        API_HIP(c->variable ? launch_density_v(c, pc) : ((c->whole_tile && c->wt_ok) ? launch_density_wt(c, pc) : launch_density(c, pc)));
+        API_HIP(c->variable ? launch_density_v(c, pc) : (use_tile_kernel(c, false) ? launch_density_wt(c, pc) : launch_density(c, pc)));
         c->density_passes++;
     }
     c->rho_valid = true; c->eos_valid = true;
@@ -242,7 +265,7 @@ int do_forces(sph_ctx *c) {
         }
     }
     { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : ((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc))); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(c->variable ? launch_forces_v(c, pc) : (use_tile_kernel(c, true) ? launch_forces_wt(c, pc, 0) : launch_forces(c, pc))); }
     c->force_passes++;
     c->rates_valid = true;
     return SPH_OK;
@@ -257,13 +280,13 @@ int do_forces_part(sph_ctx *c, int part) {
     if (part == 1) {
         if (!c->wave_class_valid) { API_HIP(launch_classify_waves(c)); c->wave_class_valid = true; }
         { Timed t(c, SPH_K_SINKACC); API_HIP(launch_sink_accel(c, pc)); }
-        { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 1) : launch_forces(c, pc, 1)); }
+        { Timed t(c, SPH_K_FORCES); API_HIP(use_tile_kernel(c, true) ? launch_forces_wt(c, pc, 1) : launch_forces(c, pc, 1)); }
         c->interior_done = true;
         c->rates_valid = false;
         return SPH_OK;
     }
     if (!c->interior_done) { c->err = "sph_forces_part: part 2 before part 1"; return SPH_ERR_STATE; }
-    { Timed t(c, SPH_K_FORCES); API_HIP((c->whole_tile && c->wt_ok_f) ? launch_forces_wt(c, pc, 2) : launch_forces(c, pc, 2)); }
+    { Timed t(c, SPH_K_FORCES); API_HIP(use_tile_kernel(c, true) ? launch_forces_wt(c, pc, 2) : launch_forces(c, pc, 2)); }
     c->interior_done = false;
     c->force_passes++;
     c->rates_valid = true;
@@ -298,8 +321,8 @@ int put_dt(sph_ctx *c, double dt, double t) {
 int drain_reports(sph_ctx *c) {
     if (c->ring_nl_valid) {
         const int32_t *rep = reinterpret_cast<const int32_t *>(c->h_pinned + 240 + 8 * (1 - c->ring_nl));
-        if (rep[0] > c->nl_cap) {
-            c->err = "neighbour list overflowed in the last build (lists grew by more than a third within one step): results are incomplete";
+        if (rep[0] > c->nl_cap || (c->tiled && rep[3] >= 65536)) {
+            c->err = "neighbour list overflowed in the last build (lists or candidate intervals grew beyond their headroom within one step): results are incomplete";
             c->ring_nl_valid = false; c->grid_valid = false; c->rho_valid = false; c->eos_valid = false; c->rates_valid = false;
             return SPH_ERR_STATE;
         }

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(BB_BLOCK) void bbox_partial(const double *__restric
     }
 }
 
-// 6 waves, one per bbox component; lanes stride over the per-block partials
-__global__ __launch_bounds__(384) void bbox_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+// 6 waves, one per bbox component; lanes stride over the per-block partials.  host_slot (pinned host memory, mapped into the
+// device's address space) gets the box and the non-finite flag directly: a separate device-to-host copy of 52 bytes costs
+// a copy kernel of ~16 us on the stream (two of them per grid build were 3 % of the bench step)
+__global__ __launch_bounds__(384) void bbox_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out,
+                                                  double *__restrict__ host_slot = nullptr, int32_t *__restrict__ flags = nullptr) {
     const int comp = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double r = comp < 3 ? INFINITY : -INFINITY;
     for (int b = lane; b < nblocks; b += 64) {
@@ -84,7 +87,13 @@ __global__ __launch_bounds__(384) void bbox_final(const double *__restrict__ par
         r = comp < 3 ? fmin(r, v) : fmax(r, v);
     }
     r = comp < 3 ? wave_min(r) : wave_max(r);
-    if (lane == 0) out[comp] = r;
+    if (lane == 0) {
+        out[comp] = r;
+        if (host_slot) {
+            host_slot[comp] = r;
+            if (comp == 0) { *reinterpret_cast<int32_t *>(host_slot + 6) = flags[0]; flags[0] = 0; }     // ... and cleared for the next build
+        }
+    }
 }
 
 // count, sum and sum of squares per axis of the live particles inside box (lo, hi): partial[b*7 + ...].  For the trimmed
@@ -424,20 +433,18 @@ int grid_rebuild(sph_ctx *c) {
 
     // ---- bounding box ---------------------------------------------------------------
     int nb = (int)std::min<int64_t>((ns + BB_BLOCK - 1) / BB_BLOCK, BB_MAX_BLOCKS);
-    GR_CHECK(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 2, st));
+    // d_flags[0] (non-finite position seen) is zero here: cleared at creation and by every bbox_final
     bbox_partial<<<dim3(nb), dim3(BB_BLOCK), 0, st>>>(c->f[SPH_F_X], c->f[SPH_F_Y], c->f[SPH_F_Z], ns, c->bbox_part, c->d_flags,
                                                       c->orig, (int32_t)c->n_owned, c->dead_below, 0);
-    bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6);
+    const int p = c->ring_bbox;
+    double *slot = c->h_pinned + 200 + 16 * p;
+    bbox_final<<<dim3(1), dim3(384), 0, st>>>(c->bbox_part, nb, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, slot, c->d_flags);
     GR_CHECK(hipGetLastError());
     // the exact box of the current positions -> read-back slot p.  Who needs it NOW (octree root boxes: variable h,
     // self-gravity, accretion; the first build of a particle set) waits for it; the plain fixed-h path takes the box of the
     // previous build, which arrived long ago, widened by one cell: particles outside the grid's box are clamped into its
     // boundary cells and still meet all their neighbours there, so the box only has to be roughly right.
-    const int p = c->ring_bbox;
-    double *slot = c->h_pinned + 200 + 16 * p;
-    GR_CHECK(hipMemcpyAsync(slot, c->bbox_part + (size_t)BB_MAX_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    GR_CHECK(hipMemcpyAsync(slot + 6, c->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GR_CHECK(hipEventRecord(c->ev_bbox[p], st));
+    GR_CHECK(hipEventRecord(c->ev_bbox[p], st));        // bbox_final wrote the slot itself (pinned memory)
     const bool stale = c->ring_bbox_valid && !c->no_stale && !c->variable && !c->gravity && !(c->p.flags & SPH_FLAG_ACCRETE_CULL);
     const double *bb = slot;
     if (stale) {

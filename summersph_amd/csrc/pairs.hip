@@ -27,6 +27,7 @@
 #include <cmath>
 
 #include "pair_common.hpp"
+#include "tile_common.hpp"
 
 namespace sph {
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
                                                            const int32_t *__restrict__ cell_start, int64_t n,
                                                            double rcut2, int32_t cap, int32_t *__restrict__ nlist,
                                                            int32_t *__restrict__ ncount, int32_t *__restrict__ wave_max,
-                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ orig,
+                                                           int32_t *__restrict__ wave_need, const int32_t *__restrict__ orig,
                                                            int32_t n_owned) {
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * PAIR_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -88,23 +89,50 @@ __global__ __launch_bounds__(PAIR_BLOCK) void nlist_kernel(GridDesc g, const dou
     const int wm = wave_max_i32(cnt);
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
-        if (wm > 0) atomicMax(&flags[1], wm);
+        wave_need[w] = wm;            // reduced by max_to_host: an atomicMax per wave on one address is serialised at the memory side
+    }
+}
+
+// largest of n ints -> *host_out (pinned host memory mapped into the device's address space); one workgroup
+__global__ __launch_bounds__(1024) void max_to_host(const int32_t *__restrict__ v, int64_t n, int32_t *__restrict__ host_out) {
+    __shared__ int s_red[16];
+    int m = 0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) m = max(m, v[k]);
+    m = wave_max_i32(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; k++) m = max(m, s_red[k]);
+        *host_out = m;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // density + EOS
 // ------------------------------------------------------------------------------------------
-// entry k of a lane's list: wave-strided dwords (PACKED = false, nlist_kernel) or the 4-packed layout of
-// the tiled list build (PACKED = true: component k%4 of the int4 at row k/4), both read in lockstep
+// entry k of a lane's list -> sorted index of the neighbour.  PACKED = false: wave-strided dwords holding the index itself
+// (nlist_kernel).  PACKED = true: the 16-bit tile slots of the tiled build (tile_common.hpp), turned into an index with the
+// plan of the lane's group of 256.  Both are read in lockstep.
 template <bool PACKED>
-__device__ __forceinline__ const int32_t *list_base(const int32_t *nlist, int64_t w, int32_t cap, int lane) {
-    return PACKED ? nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4 : nlist + ((size_t)w * cap) * 64 + lane;
-}
-template <bool PACKED>
-__device__ __forceinline__ size_t list_off(int k) {
-    return PACKED ? (size_t)(k >> 2) * 256 + (k & 3) : (size_t)k * 64;
-}
+struct ListColumn {
+    const int32_t *m32;
+    const uint16_t *m16;
+    EntryMap em;
+    __device__ __forceinline__ ListColumn(const int32_t *nlist, const int32_t *plan_f, int64_t w, int32_t cap, int lane, int self) {
+        if (PACKED) {
+            m32 = nullptr;
+            m16 = reinterpret_cast<const uint16_t *>(nlist) + (((size_t)w * (cap >> 3)) * 64 + lane) * 8;
+            em = entry_to_index(plan_f, __builtin_amdgcn_readfirstlane(self >> 8));
+        } else {
+            m32 = nlist + ((size_t)w * cap) * 64 + lane;
+            m16 = nullptr;
+            em = EntryMap{0, 0, 0, 0, 0};
+        }
+    }
+    __device__ __forceinline__ int operator()(int k) const {
+        return PACKED ? em((int)m16[(size_t)(k >> 3) * 512 + ent_pos(k & 7)]) : m32[(size_t)k * 64];
+    }
+};
 
 template <int BLOCK, bool PACKED>
 __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const double4 *__restrict__ drec,
@@ -117,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
                                                         const double *__restrict__ vz, double *__restrict__ rho,
                                                         double *__restrict__ P, double *__restrict__ cs,
                                                         double *__restrict__ frec, const int32_t *__restrict__ orig,
-                                                        int32_t n_owned) {
+                                                        int32_t n_owned, const int32_t *__restrict__ plan_f) {
     extern __shared__ double lds_w[];
     for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_w[k] = w_tab[k];
     __syncthreads();
@@ -131,21 +159,21 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     const double4 pi = drec[self];
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = list_base<PACKED>(nlist, w, cap, lane);
+    const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
     // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
     // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
     // Lanes past their own count re-read their own record (a valid address) and are masked out.
-    int j1 = 0 < cnt ? load_entry(mine + list_off<PACKED>(0)) : self;
-    int j2 = 1 < cnt ? load_entry(mine + list_off<PACKED>(1)) : self;
+    int j1 = 0 < cnt ? mine(0) : self;
+    int j2 = 1 < cnt ? mine(1) : self;
     double4 p1 = drec[j1];
     double acc = 0.0;   // sum of m_j * w(q_ij), normalised once at the end
     for (int k = 0; k < kmax; k++) {
         const double4 pj = p1;
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
+        if (k + 2 < cnt) j2 = mine(k + 2);
         if (k + 1 < cnt) p1 = drec[j1];          // idle lanes issue no gather
         density_visit(pi, pj, act, lds_w, inv_h, inv_dq, pc.nq, acc);
     }
@@ -184,7 +212,8 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
                                                        double *__restrict__ ax, double *__restrict__ ay,
                                                        double *__restrict__ az, double *__restrict__ du,
                                                        double *__restrict__ dalpha, const int32_t *__restrict__ orig,
-                                                       int32_t n_owned, const int32_t *__restrict__ wave_class, int32_t want) {
+                                                       int32_t n_owned, const int32_t *__restrict__ wave_class, int32_t want,
+                                                       const int32_t *__restrict__ plan_f) {
     extern __shared__ double lds_dw[];
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (wave_class) {       // split evaluation (multi-GPU overlap): only the waves of class `want`; a block with none leaves
@@ -207,20 +236,20 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const double4 A = fi[0], B = fi[1], Cc = fi[2];   // x y z m | vx vy vz rho/2 | c/2 alpha/2 P/rho^2 -
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
-    const int32_t *mine = list_base<PACKED>(nlist, w, cap, lane);
+    const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
     ForceSums f;
     auto dw_of = [&](double q) { return table_lerp(lds_dw, q, inv_dq, pc.nq); };
-    int j1 = 0 < cnt ? load_entry(mine + list_off<PACKED>(0)) : self;
-    int j2 = 1 < cnt ? load_entry(mine + list_off<PACKED>(1)) : self;
+    int j1 = 0 < cnt ? mine(0) : self;
+    int j2 = 1 < cnt ? mine(1) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
     double4 A1 = fj[0], B1 = fj[1], C1 = fj[2];
     for (int k = 0; k < kmax; k++) {
         const Nbr nb = nbr_of(A1, B1, C1);
         const bool act = k < cnt;
         j1 = j2;
-        if (k + 2 < cnt) j2 = load_entry(mine + list_off<PACKED>(k + 2));
+        if (k + 2 < cnt) j2 = mine(k + 2);
         if (k + 1 < cnt) {                       // idle lanes issue no gather
             fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
             A1 = fj[0]; B1 = fj[1]; C1 = fj[2];
@@ -336,13 +365,14 @@ int nlist_build(sph_ctx *c) {
     if (n == 0) return SPH_OK;
     const PairConst pc = make_pair_const(c);
     for (int attempt = 0; attempt < 8; attempt++) {
-        NL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
+        // per-wave longest lists go to wave_class (written again by classify_waves only after the build), their maximum straight to the host
         nlist_kernel<<<dim3(pair_blocks(n)), dim3(PAIR_BLOCK), 0, c->stream>>>(
             c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start, n, pc.rcut2, c->nl_cap, c->nlist,
-            c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned);
+            c->ncount, c->wave_max, c->wave_class, c->orig, (int32_t)c->n_owned);
+        max_to_host<<<dim3(1), dim3(1024), 0, c->stream>>>(c->wave_class, (n + 63) / 64, reinterpret_cast<int32_t *>(c->h_pinned + 9));
         NL_CHECK(hipGetLastError());
-        NL_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         NL_CHECK(hipStreamSynchronize(c->stream));
+        c->wave_class_valid = false;
         const int32_t mx = *reinterpret_cast<int32_t *>(c->h_pinned + 9);
         c->nl_max = mx;
         if (mx <= c->nl_cap) { c->nlist_builds++; return SPH_OK; }
@@ -356,14 +386,30 @@ int nlist_build(sph_ctx *c) {
     return SPH_ERR_STATE;
 }
 
+// workgroup size of the gather kernels: 256 threads.  64-thread workgroups (every CU busy at the reference's own problem sizes:
+// 12 000 particles are 47 workgroups of 256) were measured and lose at every size -- 12 000 particles: density 0.037 vs 0.032 ms
+// per pass, 100 000: 0.089 vs 0.048 (the 40-KB kernel table is loaded per workgroup); SPH_GATHER_BLOCK=64 keeps the A/B switch
+static int gather_block(const sph_ctx *) {
+    static const int forced = getenv("SPH_GATHER_BLOCK") ? atoi(getenv("SPH_GATHER_BLOCK")) : 0;
+    return forced == 64 ? 64 : PAIR_BLOCK;
+}
+
 hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    if (gather_block(c) == 64) {
+        auto k64 = c->packed_list ? density_kernel<64, true> : density_kernel<64, false>;
+        k64<<<dim3((unsigned)((c->n + 63) / 64)), dim3(64), lds, c->stream>>>(
+            pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->n,
+            c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P],
+            c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned, c->plan_f);
+        return hipGetLastError();
+    }
     auto k = c->packed_list ? density_kernel<PAIR_BLOCK, true> : density_kernel<PAIR_BLOCK, false>;
     k<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->n,
         c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P],
-        c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
+        c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned, c->plan_f);
     return hipGetLastError();
 }
 
@@ -380,11 +426,19 @@ hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc, bool ghosts_only) {
 hipError_t launch_forces(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
     const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    if (gather_block(c) == 64) {
+        auto k64 = c->packed_list ? forces_kernel<64, true> : forces_kernel<64, false>;
+        k64<<<dim3((unsigned)((c->n + 63) / 64)), dim3(64), lds, c->stream>>>(
+            pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
+            c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
+            part ? c->wave_class : nullptr, part == 2 ? 1 : 0, c->plan_f);
+        return hipGetLastError();
+    }
     auto k = c->packed_list ? forces_kernel<PAIR_BLOCK, true> : forces_kernel<PAIR_BLOCK, false>;
     k<<<dim3(pair_blocks(c->n)), dim3(PAIR_BLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
-        part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
+        part ? c->wave_class : nullptr, part == 2 ? 1 : 0, c->plan_f);
     return hipGetLastError();
 }
 

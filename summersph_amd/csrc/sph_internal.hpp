@@ -164,7 +164,7 @@ struct sph_ctx {
     int32_t *deal = nullptr;                        // forces_q: order of the targets within their workgroup (by list length)
     int32_t *ntail = nullptr;        // variable h: entries of the margin shell, stored from the end of the lane's column
     // variable h, re-flag pass (varh.hip): the growth of h the list in place was built to survive, the growth measured
-    double vl_grow = 1.0, h_growth = 0.0;
+    double vl_grow = 1.0, h_growth = 0.0, h_shrink = 0.0;    // h_shrink: largest h_build / h_now
     bool list_has_margin = false;    // the list in place carries the margin shell calc_smoothing reads
     int64_t nlist_reflags = 0;
     int32_t nl_max = 0; double nl_mean = 0.0;
@@ -275,6 +275,7 @@ hipError_t varh_sort_tmp_bytes(int64_t n, size_t *bytes);
 int varh_h_stats(sph_ctx *c, bool with_growth = false);   // h_max_glob, h_mean (+ h_growth against c->h_new): one read-back
 bool varh_can_reflag(const sph_ctx *c);
 int varh_nlist_reflag(sph_ctx *c);
+int varh_reflag_density(sph_ctx *c, const PairConst &pc);   // the re-flag pass and the density pass in one walk over the list
 int varh_leaf_build(sph_ctx *c);       // leaf boxes of all particles for the current positions + h
 int varh_nlist_build(sph_ctx *c);
 int varh_refresh_h(sph_ctx *c);        // only h changed: prec, reaches and per-cell max h from the new h

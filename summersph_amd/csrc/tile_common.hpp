@@ -5,6 +5,45 @@
 
 namespace sph {
 
+// ---- the fixed-h neighbour list of the tiled build: 16-bit entries --------------------------------------------------------
+// An entry is the neighbour's SLOT IN THE TILE OF ITS GROUP of 256 consecutive targets (the group of forces_q; nlist_tiled is
+// one workgroup per group): slot = base[q] + (j - lo[q]) for the interval q (offset o2 = q - 1 along the slowest grid axis)
+// that holds j, base = {0, len0, len0 + len1}.  forces_q uses an entry as it is; the 1024-target groups of density_wt and the
+// direct-gather kernels add a per-interval constant (found with two compares against base[1], base[2]).  Half the bytes of a
+// 32-bit index per entry -- the list rows are the largest stream of density_wt, and the build writes them all.
+// Layout ("ELL, wave-strided, 8-packed"): entry k of particle i = (wave w, lane l) is halfword ent_pos(k & 7) of the int4 at
+// nlist4[(w * cap/8 + k/8) * 64 + l].  ent_pos puts entries 4t .. 4t+3 of a row into the SAME half of its four words, so the
+// four lanes of a forces_q target (lane s = word s) consume a row in two trips of four consecutive entries each.
+// The three intervals of a group must stay below 65536 records together (LIST16_MAX_NEED); a context whose groups outgrow
+// that (a very dense thick domain) falls back to the untiled 32-bit list of pairs.hip for good (nlist_build_tiled).
+constexpr int LIST16_MAX_NEED = 65536;
+__device__ __host__ __forceinline__ int ent_pos(int k) { return ((k & 3) << 1) | ((k >> 2) & 1); }
+// halfword p (compile-time in the unrolled loops) of a row
+__device__ __forceinline__ int row_entry(const int4 &q, int p) {
+    const unsigned wd = (unsigned)((p >> 1) == 0 ? q.x : ((p >> 1) == 1 ? q.y : ((p >> 1) == 2 ? q.z : q.w)));
+    return (int)((p & 1) ? (wd >> 16) : (wd & 0xffffu));
+}
+// entry -> sorted index (direct gathers) or -> slot of another tile: e + add[interval of e]
+struct EntryMap {
+    int b1, b2;           // base[1], base[2] of the forces group the list column belongs to
+    int a0, a1, a2;       // what to add to an entry of interval 0, 1, 2 (scalars: an array member went to scratch memory)
+    // written as two conditional increments: the nested select `e >= b2 ? a2 : (e >= b1 ? a1 : a0)` is turned into a
+    // three-entry table in scratch memory by the compiler (one scratch load per visit)
+    __device__ __forceinline__ int operator()(int e) const {
+        return (int)((unsigned)e + (unsigned)a0 + (e >= b1 ? (unsigned)a1 - (unsigned)a0 : 0u) + (e >= b2 ? (unsigned)a2 - (unsigned)a1 : 0u));
+    }
+};
+// plan_f record of group g: {lo0, lo1, lo2, len0, len1, len2, need, 0}; sorted index = e + lo[q] - base[q]
+__device__ __forceinline__ EntryMap entry_to_index(const int32_t *__restrict__ plan_f, int64_t g) {
+    const int32_t *p = plan_f + 8 * (size_t)g;
+    const int4 a = *reinterpret_cast<const int4 *>(p);
+    const int len1 = p[4];
+    EntryMap m;
+    m.b1 = a.w; m.b2 = a.w + len1;
+    m.a0 = a.x; m.a1 = (int)((unsigned)a.y - (unsigned)m.b1); m.a2 = (int)((unsigned)a.z - (unsigned)m.b2);
+    return m;
+}
+
 struct TileMap {
     int lo[3], len[3], base[3];
     int need;             // records of the three intervals together

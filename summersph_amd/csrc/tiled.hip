@@ -10,8 +10,9 @@
 // So a workgroup stages those intervals once, side by side, in LDS with coalesced loads and the pair loop -- the same
 // lock-step list walk as pairs.hip -- reads its neighbours from the tile.
 //
-// Neighbour list ("ELL, wave-strided, 4-packed"): entry k of particle i = (wave w, lane l) is component k%4 of the int4
-// at nlist4[(w*cap4 + k/4)*64 + l].
+// Neighbour list ("ELL, wave-strided, 8-packed", tile_common.hpp): 16-bit entries = the neighbour's slot in the tile of the
+// target's group of 256; entry k of particle i = (wave w, lane l) is halfword ent_pos(k%8) of the int4 at
+// nlist4[(w*cap/8 + k/8)*64 + l].
 //
 // Replaces (citations: /root/reference/SUMMER_SPH.f90, "[F]"): the same reference code as pairs.hip --
 // density_tree_search/get_density [F]:398-457, get_pressure_and_sound_speed [F]:459-468,
@@ -82,9 +83,10 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                                                   int4 *__restrict__ nlist4, int32_t *__restrict__ ncount,
                                                   int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
                                                   const int32_t *__restrict__ orig, int32_t n_owned, int2 *__restrict__ deal,
-                                                  int32_t *__restrict__ plan_f, int32_t tcap_f) {
+                                                  int32_t *__restrict__ plan_f) {
     __shared__ double4 tile[T_NL];
-    __shared__ int s_lo[4], s_hi[4];
+    __shared__ int4 rowbuf[TB];                       // per lane: the row being filled, eight 16-bit entries (packing them in
+    __shared__ int s_lo[4], s_hi[4];                  // registers cost the accept path 17 vector instructions instead of 6)
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * TB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t w = i >> 6;
@@ -92,11 +94,12 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     const double4 pi = drec[i < n ? i : n - 1];
     int cc[3];
     cell_coords(g, pi.x, pi.y, pi.z, cc);
-    const int cap4 = cap >> 2;
-    int4 *mine = nlist4 + ((size_t)w * cap4) * 64 + lane;
+    const int cap8 = cap >> 3;
+    int4 *mine = nlist4 + ((size_t)w * cap8) * 64 + lane;
+    uint16_t *myrow = reinterpret_cast<uint16_t *>(&rowbuf[threadIdx.x]);
     int cnt = 0;
-    int4 buf = make_int4(0, 0, 0, 0);
     int plo[3], plen[3];
+    int base = 0;                                     // tile slot of the current interval's first record
 
 #pragma unroll
     for (int o2 = -1; o2 <= 1; o2++) {
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
         int lo, hi;
         block_interval(r, s_lo, s_hi, lo, hi);
         plo[o2 + 1] = lo; plen[o2 + 1] = hi > lo ? hi - lo : 0;
+        const int slot0 = base - lo;                  // entry of candidate j: its slot in this group's tile
         for (int cb = lo; cb < hi; cb += T_NL) {
             const int ce = min(cb + T_NL, hi);
             __syncthreads();
@@ -118,28 +122,30 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                     const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const double r2 = dx * dx + dy * dy + dz * dz;
                     if (r2 <= rcut2 && j != (int)i) {
-                        const int q = cnt & 3;              // selects, not branches: the accept path runs for every third candidate
-                        buf.x = q == 0 ? j : buf.x; buf.y = q == 1 ? j : buf.y; buf.z = q == 2 ? j : buf.z; buf.w = q == 3 ? j : buf.w;
-                        if (q == 3 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;
+                        myrow[ent_pos(cnt & 7)] = (uint16_t)(j + slot0);
+                        if ((cnt & 7) == 7 && cnt < cap) mine[(size_t)(cnt >> 3) * 64] = rowbuf[threadIdx.x];
                         cnt++;
                     }
                 }
             }
         }
+        base += plen[o2 + 1];
     }
-    if ((cnt & 3) != 0 && cnt < cap) mine[(size_t)(cnt >> 2) * 64] = buf;     // last, partly filled quad
+    if ((cnt & 7) != 0 && cnt < cap) mine[(size_t)(cnt >> 3) * 64] = rowbuf[threadIdx.x];     // last, partly filled row (its tail: stale entries, never read)
     if (i < n) ncount[i] = live ? cnt : 0;
     const int wm = wave_max_i32(live ? cnt : 0);
-    if (lane == 0 && (w << 6) < n) {
-        wave_max[w] = min(wm, cap);
-        if (wm > 0) atomicMax(&flags[1], wm);
-    }
-    if (plan_f && threadIdx.x == 0) {
-        // the three intervals staged above are the tile of forces_q for this group of 256 targets: its plan for free
+    if (lane == 0 && (w << 6) < n) wave_max[w] = min(wm, cap);
+    // the group's longest list and tile need go into its plan record; plan_reduce_kernel forms the maxima the host reads
+    // (one atomic per WAVE on one address -- 15 625 of them at 1e6 particles -- is what the memory side serialises)
+    __syncthreads();
+    if (lane == 0) s_lo[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the three intervals staged above: what the entries are relative to, and the tile of forces_q for this group
         int32_t *p = plan_f + 8 * (size_t)xcd_chunk(blockIdx.x, gridDim.x);
         const int need = plen[0] + plen[1] + plen[2];
-        p[0] = plo[0]; p[1] = plo[1]; p[2] = plo[2]; p[3] = plen[0]; p[4] = plen[1]; p[5] = plen[2]; p[6] = need; p[7] = 0;
-        if (need > tcap_f) atomicAdd(&flags[5], 1);
+        p[0] = plo[0]; p[1] = plo[1]; p[2] = plo[2]; p[3] = plen[0]; p[4] = plen[1]; p[5] = plen[2]; p[6] = need;
+        p[7] = max(max(s_lo[0], s_lo[1]), max(s_lo[2], s_lo[3]));
     }
     if (deal) {
         // forces_q deals the 256 targets of this workgroup (= one of its groups) to its lanes in order of list length,
@@ -218,10 +224,9 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
     m.need = total;
 }
 
-__device__ __forceinline__ size_t poff(int k) { return (size_t)(k >> 2) * 256 + (k & 3); }
-
 template <int BS>
 __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
+                                                 const int32_t *__restrict__ plan_f,
                                                  const double4 *__restrict__ drec, const int32_t *__restrict__ nlist,
                                                  int32_t cap, const int32_t *__restrict__ ncount, const int32_t *__restrict__ wave_max,
                                                  const double *__restrict__ w_tab,
@@ -256,37 +261,61 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
         const double4 pi = drec[self];
         const int cnt = live ? min(ncount[i], cap) : 0;
         const int kmax = (i & ~(int64_t)63) < n ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+        // the list entries are slots of the tile of the wave's own group of 256 (plan_f): into THIS tile (the union of four
+        // such groups) or into the sorted order (direct gathers) with one constant per interval
+        EntryMap em = entry_to_index(plan_f, __builtin_amdgcn_readfirstlane(self >> 8));      // wave-uniform: scalar loads
+        if (fits) {
+            em.a0 = (int)((unsigned)em.a0 + (unsigned)tm.base[0] - (unsigned)tm.lo[0]);
+            em.a1 = (int)((unsigned)em.a1 + (unsigned)tm.base[1] - (unsigned)tm.lo[1]);
+            em.a2 = (int)((unsigned)em.a2 + (unsigned)tm.base[2] - (unsigned)tm.lo[2]);
+        }
         __syncthreads();
         double acc = 0.0;
+        const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 3)) * 64 + lane;
+        const int nrow = (kmax + 7) >> 3;
+        // list rows as int4 (eight 16-bit entries), fetched two rows ahead with wave-uniform, unconditional loads.  A row is
+        // walked as two halves of four entries -- entries 4 hh .. 4 hh + 3 are the hh-th halfwords of its four words -- so that
+        // the loop body stays four visits long (eight unrolled visits cost 35 more registers and spilled)
+        auto half_entry = [](int wd, int sh) { return (int)(((unsigned)wd >> sh) & 0xffffu); };
         if (fits && kmax > 0) {
-            // list rows as int4 (four entries), fetched two rows ahead with wave-uniform, unconditional loads
-            const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
-            const int nrow = (kmax + 3) >> 2;
             int4 qa = load_row(mine4);
             int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
-            double4 p1 = tile[0 < cnt ? tm.slot(qa.x) : 0];
+            double4 p1 = tile[0 < cnt ? em(half_entry(qa.x, 0)) : 0];
             for (int r = 0; r < nrow; r++) {
                 const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
+#pragma unroll 1
+                for (int hh = 0; hh < 2; hh++) {
+                    const int sh = hh << 4;
+                    const int nxt = hh == 0 ? half_entry(qa.x, 16) : half_entry(qb.x, 0);      // the entry after this half's last
 #pragma unroll
-                for (int v = 0; v < 4; v++) {                 // whole rows, no trip-count test: the up to three trips past the
-                    const int k = 4 * r + v;                  // wave's longest list are masked like any idle lane, and without
-                    const double4 pj = p1;                    // the branch the pipeline registers rotate by renaming, not by moves
-                    p1 = tile[k + 1 < cnt ? tm.slot(v < 3 ? comp4(qa, v + 1) : qb.x) : 0];
-                    density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                    for (int v = 0; v < 4; v++) {             // whole halves, no trip-count test: the trips past the wave's
+                        const int k = 8 * r + 4 * hh + v;     // longest list are masked like any idle lane
+                        const double4 pj = p1;
+                        p1 = tile[k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : 0];
+                        density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                    }
                 }
                 qa = qb; qb = qc;
             }
         } else if (!fits && kmax > 0) {
-            const int32_t *mine = nlist + (((size_t)w * (cap >> 2)) * 64 + lane) * 4;
-            int j1 = 0 < cnt ? load_entry(mine + poff(0)) : self;
-            int j2 = 1 < cnt ? load_entry(mine + poff(1)) : self;
-            double4 p1 = drec[j1];
-            for (int k = 0; k < kmax; k++) {
-                const double4 pj = p1;
-                j1 = j2;
-                if (k + 2 < cnt) j2 = load_entry(mine + poff(k + 2));
-                if (k + 1 < cnt) p1 = drec[j1];
-                density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+            int4 qa = load_row(mine4);
+            int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
+            double4 p1 = drec[0 < cnt ? em(half_entry(qa.x, 0)) : self];
+            for (int r = 0; r < nrow; r++) {
+                const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
+#pragma unroll 1
+                for (int hh = 0; hh < 2; hh++) {
+                    const int sh = hh << 4;
+                    const int nxt = hh == 0 ? half_entry(qa.x, 16) : half_entry(qb.x, 0);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int k = 8 * r + 4 * hh + v;
+                        const double4 pj = p1;
+                        if (k + 1 < cnt) p1 = drec[em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt)];
+                        density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                    }
+                }
+                qa = qb; qb = qc;
             }
         }
         if (live) density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
@@ -367,36 +396,49 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
         const int cnt = live ? dl.y : 0;
         __syncthreads();
-        const int nrow = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));
+        // a trip = four consecutive entries of the target's list, one per lane: lane s reads word s of the list row (eight
+        // 16-bit entries), its low half in the even trip, its high half in the odd one (ent_pos, tile_common.hpp)
+        const int ntrip = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));
         ForceSums f;
-        // this lane's entries: component `sub` of the rows of target i's list column
-        const int32_t *lp = nlist + (((size_t)(self >> 6) * (cap >> 2)) * 64 + (self & 63)) * 4 + sub;
-        if (nrow > 0) {
-            int ea = lp[0];
-            int eb = lp[(size_t)min(1, nrow - 1) * 256];
-            int ec = lp[(size_t)min(2, nrow - 1) * 256];
+        const uint32_t *lp = reinterpret_cast<const uint32_t *>(nlist) + (((size_t)(self >> 6) * (cap >> 3)) * 64 + (self & 63)) * 4 + sub;
+        if (ntrip > 0) {
+            const int nrow = (ntrip + 1) >> 1;
+            uint32_t wa = lp[0];
+            uint32_t wb = lp[(size_t)min(1, nrow - 1) * 256];
             if (fits) {
-                const double2 *rp = tile + q_unit(sub < cnt ? tm.slot(ea) : 0);
+                // an entry IS the neighbour's slot in this group's tile
+                const double2 *rp = tile + q_unit(sub < cnt ? (int)(wa & 0xffffu) : 0);
                 double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
                 for (int r = 0; r < nrow; r++) {
-                    const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
-                    const int k = 4 * r + sub;
-                    rp = tile + q_unit(k + 4 < cnt ? tm.slot(eb) : 0);
-                    r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
-                    eb = ec;
-                    ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
-                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    const uint32_t wc = lp[(size_t)min(r + 2, nrow - 1) * 256];
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        if (hf == 1 && 2 * r + 1 >= ntrip) break;        // wave-uniform: the odd trip of the last row
+                        const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
+                        const int k = 4 * (2 * r + hf) + sub;
+                        const int en = hf == 0 ? (int)(wa >> 16) : (int)(wb & 0xffffu);
+                        rp = tile + q_unit(k + 4 < cnt ? en : 0);
+                        r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
+                        force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    }
+                    wa = wb; wb = wc;
                 }
             } else {
-                int j = sub < cnt ? ea : self;
+                const EntryMap em = entry_to_index(plan, group);
+                int j = sub < cnt ? em((int)(wa & 0xffffu)) : self;
                 double4 A1 = fg[(size_t)j * 3], B1 = fg[(size_t)j * 3 + 1], C1 = fg[(size_t)j * 3 + 2];
                 for (int r = 0; r < nrow; r++) {
-                    const Nbr nb = nbr_of(A1, B1, C1);
-                    const int k = 4 * r + sub;
-                    if (k + 4 < cnt) { j = eb; A1 = fg[(size_t)j * 3]; B1 = fg[(size_t)j * 3 + 1]; C1 = fg[(size_t)j * 3 + 2]; }
-                    eb = ec;
-                    ec = lp[(size_t)min(r + 3, nrow - 1) * 256];
-                    force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    const uint32_t wc = lp[(size_t)min(r + 2, nrow - 1) * 256];
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        if (hf == 1 && 2 * r + 1 >= ntrip) break;
+                        const Nbr nb = nbr_of(A1, B1, C1);
+                        const int k = 4 * (2 * r + hf) + sub;
+                        const int en = hf == 0 ? (int)(wa >> 16) : (int)(wb & 0xffffu);
+                        if (k + 4 < cnt) { j = em(en); A1 = fg[(size_t)j * 3]; B1 = fg[(size_t)j * 3 + 1]; C1 = fg[(size_t)j * 3 + 2]; }
+                        force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                    }
+                    wa = wb; wb = wc;
                 }
             }
         }
@@ -429,30 +471,54 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
 }
 
 
-// The tile plan of every workgroup of BS consecutive targets, made once per list build and read by every evaluation kernel
-// of that geometry (two density and two force passes per position set): plan[8 g + ...] = {lo0, lo1, lo2, len0, len1, len2,
-// need, 0}.  Workgroups whose three intervals do not fit a tile of tcap records are counted in *misfit.  (Computing the
-// intervals inside the evaluation kernels cost them 18 dependent cell-table reads per thread, two wave reductions and a
-// barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
-// the plan of a 1024-target group of density_wt = the union of the plans of its four 256-target groups (nlist_tiled writes those)
-__global__ __launch_bounds__(256) void plan_merge_kernel(int64_t ngroups_d, int64_t ngroups_f, const int32_t *__restrict__ plan_f, int32_t tcap_d,
-                                                         int32_t *__restrict__ plan_d, int32_t *__restrict__ misfit) {
-    const int64_t gd = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gd >= ngroups_d) return;
-    int need = 0;
-    int32_t *p = plan_d + 8 * (size_t)gd;
-    for (int q = 0; q < 3; q++) {
-        int lo = 0x7fffffff, hi = 0;
+// What the host reads of a build, from the plan records nlist_tiled left (plan_f[8 g + ...] = {lo0, lo1, lo2, len0, len1, len2,
+// need, longest list of the group}): the longest list, the groups of density_wt / forces_q whose tile does not fit, the largest
+// tile need; and, for the whole-tile kernels, the plan of every 1024-target group of density_wt = the union of the plans of
+// its four 256-target groups (plan_d).
+// (Computing the intervals inside the evaluation kernels cost them 18 dependent cell-table reads per thread, two wave
+// reductions and a barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
+__global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, int64_t ngroups_f, const int32_t *__restrict__ plan_f, int32_t tcap_d,
+                                                           int32_t tcap_f, int32_t *__restrict__ plan_d, int32_t *__restrict__ report) {
+    // ONE workgroup strides over the density groups (977 at 1e6 particles) and writes the four numbers straight into the host's
+    // report slot (pinned memory mapped into the device's address space): no atomics, no device-to-host copy kernels
+    __shared__ int s_red[4][16];
+    int mx_list = 0, mx_need = 0, misfit_f = 0, misfit_d = 0;
+    for (int64_t gd = threadIdx.x; gd < ngroups_d; gd += 1024) {
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
         for (int64_t gf = 4 * gd; gf < std::min<int64_t>(4 * gd + 4, ngroups_f); gf++) {
-            const int l = plan_f[8 * gf + q], len = plan_f[8 * gf + 3 + q];
-            if (len > 0) { lo = min(lo, l); hi = max(hi, l + len); }
+            const int4 a = *reinterpret_cast<const int4 *>(plan_f + 8 * gf), b = *reinterpret_cast<const int4 *>(plan_f + 8 * gf + 4);
+            const int l[3] = {a.x, a.y, a.z}, len[3] = {a.w, b.x, b.y};
+            for (int q = 0; q < 3; q++)
+                if (len[q] > 0) { lo[q] = min(lo[q], l[q]); hi[q] = max(hi[q], l[q] + len[q]); }
+            mx_need = max(mx_need, b.z); mx_list = max(mx_list, b.w);
+            misfit_f += b.z > tcap_f ? 1 : 0;
         }
-        const int len = hi > lo ? hi - lo : 0;
-        p[q] = lo; p[3 + q] = len;
-        need += len;
+        if (plan_d) {
+            int need = 0;
+            int32_t *p = plan_d + 8 * (size_t)gd;
+            for (int q = 0; q < 3; q++) {
+                const int len = hi[q] > lo[q] ? hi[q] - lo[q] : 0;
+                p[q] = lo[q]; p[3 + q] = len;
+                need += len;
+            }
+            p[6] = need; p[7] = 0;
+            misfit_d += need > tcap_d ? 1 : 0;
+        }
     }
-    p[6] = need; p[7] = 0;
-    if (need > tcap_d) atomicAdd(misfit, 1);
+    for (int o = 32; o > 0; o >>= 1) {
+        mx_list = max(mx_list, __shfl_xor(mx_list, o, 64)); mx_need = max(mx_need, __shfl_xor(mx_need, o, 64));
+        misfit_f += __shfl_xor(misfit_f, o, 64); misfit_d += __shfl_xor(misfit_d, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        s_red[0][wv] = mx_list; s_red[1][wv] = misfit_d; s_red[2][wv] = misfit_f; s_red[3][wv] = mx_need;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int k = 0; k < 16; k++) { r0 = max(r0, s_red[0][k]); r1 += s_red[1][k]; r2 += s_red[2][k]; r3 = max(r3, s_red[3][k]); }
+        report[0] = r0; report[1] = r1; report[2] = r2; report[3] = r3;      // {longest list, misfits density, misfits forces, largest need}
+    }
 }
 
 inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
@@ -486,6 +552,16 @@ int32_t tile_cap_q(int nq) {
         }                                                                   \
     } while (0)
 
+// a context whose groups outgrow the 16-bit entries leaves the tiled path for good: the untiled 32-bit list of pairs.hip
+static int leave_tiled_path(sph_ctx *c) {
+    c->tiled = false; c->whole_tile = false; c->packed_list = false;
+    c->wt_ok = c->wt_ok_f = false; c->wt_fit_pct = c->wt_fit_pct_f = -1;
+    c->ring_nl_valid = false;
+    ctx_free(c, c->nlist);
+    if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
+    return nlist_build(c);
+}
+
 int nlist_build_tiled(sph_ctx *c) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
@@ -493,11 +569,11 @@ int nlist_build_tiled(sph_ctx *c) {
     const unsigned d_blocks = (unsigned)((n + WT_BS - 1) / WT_BS), f_blocks = (unsigned)((n + FQ_T - 1) / FQ_T);
     auto regrow = [&](int32_t want) {
         ctx_free(c, c->nlist);
-        c->nl_cap = (want + 3) & ~3;
-        if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 64, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }
+        c->nl_cap = (want + 7) & ~7;
+        if (ctx_alloc(c, &c->nlist, (size_t)c->nl_waves_cap * c->nl_cap * 32, "neighbour list") != SPH_OK) { c->nl_cap = 0; return SPH_ERR_NOMEM; }     // 16-bit entries
         return SPH_OK;
     };
-    // what a build reports: {longest list, misfits of the density geometry, misfits of the forces geometry}
+    // what a build reports: {longest list, misfits of the density geometry, misfits of the forces geometry, largest tile need}
     auto digest = [&](const int32_t *rep) {
         c->nl_max = rep[0];
         if (c->whole_tile) {
@@ -511,7 +587,8 @@ int nlist_build_tiled(sph_ctx *c) {
     };
     // Steady state: the report of the PREVIOUS build (it arrived long ago) is read instead of waiting for this one's.  The
     // list keeps a third of headroom, so a list that overflows within one step (which the dt control all but excludes) is
-    // an error reported one build late, not a silent truncation.
+    // an error reported one build late, not a silent truncation.  The same for the 16-bit entries: the context leaves the
+    // tiled path when a group's intervals reach HALF of what an entry can address.
     const bool trusted = c->ring_nl_valid && !c->no_stale;
     const int p = c->ring_nl;
     int32_t *slot = reinterpret_cast<int32_t *>(c->h_pinned + 240 + 8 * p);
@@ -519,31 +596,30 @@ int nlist_build_tiled(sph_ctx *c) {
         TL_CHECK(hipEventSynchronize(c->ev_nl[1 - p]));
         const int32_t *prev = reinterpret_cast<const int32_t *>(c->h_pinned + 240 + 8 * (1 - p));
         if (prev[0] > c->nl_cap) { c->err = "neighbour list overflowed in the previous build (lists grew by more than a third within one step)"; return SPH_ERR_STATE; }
+        if (prev[3] >= LIST16_MAX_NEED) { c->err = "neighbour list: a group's candidate intervals outgrew the 16-bit entries within one step"; return SPH_ERR_STATE; }
+        if (2 * (int64_t)prev[3] >= LIST16_MAX_NEED) return leave_tiled_path(c);
         digest(prev);
         if (4 * (int64_t)prev[0] > 3 * (int64_t)c->nl_cap) { const int st = regrow(prev[0] + prev[0] / 2 + 8); if (st != SPH_OK) return st; }
     }
     for (int attempt = 0; attempt < 8; attempt++) {
-        // flags[1]: longest list; flags[4], flags[5]: how many workgroups of density_wt / forces_q do not fit their tile
-        // (one fill: [2] and [3] belong to the sink code, which sets them before every use)
-        TL_CHECK(hipMemsetAsync(c->d_flags + 1, 0, 5 * sizeof(int32_t), c->stream));
         nlist_tiled<<<dim3(tb_blocks(n)), dim3(TB), 0, c->stream>>>(c->grid, reinterpret_cast<const double4 *>(c->drec), c->cell_start,
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
                                                                     c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned,
                                                                     c->whole_tile ? reinterpret_cast<int2 *>(c->deal) : nullptr,
-                                                                    c->whole_tile ? c->plan_f : nullptr, tile_cap_q(pc.nq));
+                                                                    c->plan_f);
         TL_CHECK(hipGetLastError());
-        if (c->whole_tile) {
+        {
             const int64_t ngd = (n + WT_BS - 1) / WT_BS, ngf = (n + FQ_T - 1) / FQ_T;
-            plan_merge_kernel<<<dim3((unsigned)((ngd + 255) / 256)), dim3(256), 0, c->stream>>>(ngd, ngf, c->plan_f, tile_cap(pc.nq, 4, true), c->plan_d,
-                                                                                             c->d_flags + 4);
+            plan_reduce_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(
+                ngd, ngf, c->plan_f, c->whole_tile ? tile_cap(pc.nq, 4, true) : 0, c->whole_tile ? tile_cap_q(pc.nq) : LIST16_MAX_NEED,
+                c->whole_tile ? c->plan_d : nullptr, slot);
             TL_CHECK(hipGetLastError());
         }
-        TL_CHECK(hipMemcpyAsync(slot, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        TL_CHECK(hipMemcpyAsync(slot + 1, c->d_flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         TL_CHECK(hipEventRecord(c->ev_nl[p], c->stream));
         if (trusted) break;
         TL_CHECK(hipStreamSynchronize(c->stream));
         c->host_syncs++;
+        if (2 * (int64_t)slot[3] >= LIST16_MAX_NEED) return leave_tiled_path(c);
         digest(slot);
         const int32_t mx = slot[0];
         if (4 * (int64_t)mx <= 3 * (int64_t)c->nl_cap) break;            // fits, with the headroom the steady state relies on
@@ -588,7 +664,7 @@ hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
     const unsigned grid = persistent_grid(c, ngroups);
     density_wt<WT_BS><<<dim3(grid), dim3(WT_BS), lds, c->stream>>>(
-        pc, tcap, (int32_t)ngroups, c->plan_d, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
+        pc, tcap, (int32_t)ngroups, c->plan_d, c->plan_f, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
         c->w_tab, c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
         c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
     return hipGetLastError();

@@ -58,29 +58,30 @@ __device__ __forceinline__ double wave_sumd(double v) {
 // the build (shrinking only removes pairs; a measured optimum: 1.05 is used less often, 1.1 makes build and margin larger)
 constexpr double REFLAG_GROW = 1.07;
 
-// max h, sum h and -- with h_prev, the lengths the current list was built with -- the largest growth h / h_prev
+// max h, sum h and -- with h_prev, the lengths the current list was built with -- the largest growth h / h_prev and the
+// largest shrinkage (stored as the largest h_prev / h)
 __global__ __launch_bounds__(VBLOCK) void h_stats_partial(const double *__restrict__ h, const double *__restrict__ h_prev, int64_t n,
                                                           double *__restrict__ part) {
-    __shared__ double sm[3][VBLOCK / WAVE];
-    double mx = 0.0, su = 0.0, gr = 0.0;
+    __shared__ double sm[4][VBLOCK / WAVE];
+    double mx = 0.0, su = 0.0, gr = 0.0, sh = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * VBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VBLOCK) {
         mx = fmax(mx, h[i]); su += h[i];
-        if (h_prev) gr = fmax(gr, h[i] / h_prev[i]);
+        if (h_prev) { gr = fmax(gr, h[i] / h_prev[i]); sh = fmax(sh, h_prev[i] / h[i]); }
     }
-    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr);
-    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mx; sm[1][threadIdx.x >> 6] = su; sm[2][threadIdx.x >> 6] = gr; }
+    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr); sh = wave_maxd(sh);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mx; sm[1][threadIdx.x >> 6] = su; sm[2][threadIdx.x >> 6] = gr; sm[3][threadIdx.x >> 6] = sh; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < VBLOCK / WAVE; k++) { mx = fmax(mx, sm[0][k]); su += sm[1][k]; gr = fmax(gr, sm[2][k]); }
-        part[3 * blockIdx.x] = mx; part[3 * blockIdx.x + 1] = su; part[3 * blockIdx.x + 2] = gr;
+        for (int k = 1; k < VBLOCK / WAVE; k++) { mx = fmax(mx, sm[0][k]); su += sm[1][k]; gr = fmax(gr, sm[2][k]); sh = fmax(sh, sm[3][k]); }
+        part[4 * blockIdx.x] = mx; part[4 * blockIdx.x + 1] = su; part[4 * blockIdx.x + 2] = gr; part[4 * blockIdx.x + 3] = sh;
     }
 }
 
 __global__ void h_stats_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
-    double mx = 0.0, su = 0.0, gr = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) { mx = fmax(mx, part[3 * b]); su += part[3 * b + 1]; gr = fmax(gr, part[3 * b + 2]); }
-    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr);
-    if (threadIdx.x == 0) { out[0] = mx; out[1] = su; out[2] = gr; }
+    double mx = 0.0, su = 0.0, gr = 0.0, sh = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) { mx = fmax(mx, part[4 * b]); su += part[4 * b + 1]; gr = fmax(gr, part[4 * b + 2]); sh = fmax(sh, part[4 * b + 3]); }
+    mx = wave_maxd(mx); su = wave_sumd(su); gr = wave_maxd(gr); sh = wave_maxd(sh);
+    if (threadIdx.x == 0) { out[0] = mx; out[1] = su; out[2] = gr; out[3] = sh; }
 }
 
 // ---- octree leaf boxes ----------------------------------------------------------------------------
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
                                                         const int32_t *__restrict__ cell_start, const double *__restrict__ cell_hmax,
                                                         int64_t n, int32_t n_owned, int32_t cap, int32_t *__restrict__ nlist,
                                                         int32_t *__restrict__ ncount, int32_t *__restrict__ ntail,
-                                                        int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
+                                                        int32_t *__restrict__ wave_max, int32_t *__restrict__ wave_need,
                                                         const int32_t *__restrict__ number) {
     __shared__ double4 tile[T_NV], tile_l[T_NV];
     __shared__ int32_t tile_o[T_NV];
@@ -382,7 +383,21 @@ __global__ __launch_bounds__(VBLOCK) void nlist_v_tiled(GridDesc g, int R, doubl
     const int need = wave_max_i32(live ? 4 * (((cnt + 3) >> 2) + ((tcnt + 3) >> 2)) : 0);
     if (lane == 0 && (w << 6) < n) {
         wave_max[w] = min(wm, cap);
-        if (need > 0) atomicMax(&flags[1], need);
+        wave_need[w] = need;          // reduced by max_to_host (an atomicMax per wave on ONE address is serialised at the memory side)
+    }
+}
+
+// largest of n ints -> *host_out (pinned host memory mapped into the device's address space); one workgroup
+__global__ __launch_bounds__(1024) void max_to_host(const int32_t *__restrict__ v, int64_t n, int32_t *__restrict__ host_out) {
+    __shared__ int s_red[16];
+    int m = 0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) m = max(m, v[k]);
+    m = wave_max_i32(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; k++) m = max(m, s_red[k]);
+        *host_out = m;
     }
 }
 
@@ -672,6 +687,161 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     density_epilogue_v(pc, i, pi, hi, d, lw[0], u, alpha, vx, vy, vz, rho, omega, P, cs, frec);
 }
 
+// ---- re-flag pass and density pass in ONE walk over the list (start of a step: only h is newer than the list) ---------
+// nlist_v_reflag and density_v_kernel walk the same rows and gather the same neighbours one after the other; here every
+// entry is visited once: its flags for the new lengths are settled as in nlist_v_reflag (and written back for forces_v),
+// and when they include D the entry is added to the density sums on the spot.  Pass 1 = the D/F entries where they stand,
+// pass 2 = the margin shell, whose promoted entries are appended behind them (and summed too).  The order in which a
+// particle's neighbours are summed is the list's, with promoted entries last -- as for a re-flagged list.
+// Measured (1e6 bench disc, ms per start of step): separate passes 0.985 + 0.33, this kernel 1.20.  It is bound by the latency
+// of its dependent gathers at three waves per SIMD (160 VGPRs), not by their number: a variant in which the build marked the
+// entries whose flags cannot change while every h stays within 3 % (no gather for them at all; forced on for the timing) ran
+// 1.25 ms and cost the build 0.13 ms per step for the marking -- out of the tree again.
+struct FusedStage {           // an entry between classification and its flags
+    ReflagStage st;
+    double4 pm;               // {x, y, z, m} of the partner (for the density visit)
+};
+
+__global__ __launch_bounds__(VBLOCK) void reflag_density_kernel(PairConst pc, const double4 *__restrict__ prec, const double4 *__restrict__ lrec,
+                                                                const double4 *__restrict__ drec, const double *__restrict__ mass,
+                                                                const int32_t *__restrict__ orig, int64_t n, int32_t n_owned, int32_t cap,
+                                                                int32_t *__restrict__ nlist, int32_t *__restrict__ ncount,
+                                                                const int32_t *__restrict__ ntail, int32_t *__restrict__ wave_max,
+                                                                const int32_t *__restrict__ number, const double *__restrict__ w_tab,
+                                                                const double *__restrict__ dw_tab, const double *__restrict__ u,
+                                                                const double *__restrict__ alpha, const double *__restrict__ vx,
+                                                                const double *__restrict__ vy, const double *__restrict__ vz,
+                                                                double *__restrict__ rho, double *__restrict__ omega,
+                                                                double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec) {
+    extern __shared__ double lds[];
+    double *lw = lds, *ldw = lds + (pc.nq + 1);
+    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
+    __syncthreads();
+    const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
+    if ((i & ~(int64_t)63) >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 6;
+    const bool live = i < n && orig[i] < n_owned;
+    const int self = i < n ? (int)i : (int)(n - 1);
+    const double4 pi = prec[self], li = lrec[self];
+    const double4 pim = drec[self];                           // {x, y, z, m_i}: the density sums are formed as density_v_kernel forms them
+    const int oi = number ? number[orig[self]] : orig[self];
+    const double hi = pi.w;
+    const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
+    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
+    const int cap4 = cap >> 2;
+    int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * cap4) * 64 + lane;
+    const int cnt_a = live ? min(ncount[i], cap) : 0, tcnt_a = live ? ntail[i] : 0;
+    DensSumsV d;
+
+    // the record an entry needs: {x, y, z, h_j} to settle its flags, m_j for the sum
+    auto fetch = [&](int e, bool act, double4 &rec, double &mj) {
+        const int j = e & IDX_MASK;
+        rec = prec[act ? j : self];
+        mj = act ? mass[j] : 0.0;
+    };
+    auto classify = [&](int e, bool act, const double4 &rec, double mj, FusedStage &fs) {
+        reflag_classify(pi, li, ri2, act, e & IDX_MASK, rec, lrec, orig, fs.st);
+        fs.pm = make_double4(rec.x, rec.y, rec.z, mj);
+    };
+    // flags of the entry classified a trip ago; a D entry joins the sums here
+    auto finish = [&](const FusedStage &fs) -> int {
+        const int ent = reflag_finish(pi, oi, fs.st, number);
+        density_visit_v(pim, fs.pm, ((uint32_t)ent & FLAG_D) != 0, lw, ldw, inv_h, inv_dq, pc.nq, d);
+        return ent;
+    };
+
+    // pass 1: the D/F entries, in place
+    int4 last = make_int4(0, 0, 0, 0);                      // the row that holds entry cnt_a (where pass 2 appends)
+    const int kmax = wave_max_i32(cnt_a);
+    if (kmax > 0) {
+        const int nrow = (kmax + 3) >> 2;
+        int4 qa = load_row(mine);
+        int4 qb = load_row(mine + (size_t)min(1, nrow - 1) * 64);
+        int e1 = 0 < cnt_a ? qa.x : self;
+        double4 p1; double m1;
+        fetch(e1, 0 < cnt_a, p1, m1);
+        FusedStage fs;
+        fs.st.j = 0; fs.st.cls = 0; fs.st.d = false; fs.st.rji = false; fs.st.lj = li; fs.st.oj = 0; fs.pm = pim;
+        int4 outp = make_int4(0, 0, 0, 0);                  // the previous row, waiting for its fourth entry
+        int4 qprev = make_int4(0, 0, 0, 0);                 // ... as it stands in memory: most rows come out unchanged and are not written
+        auto same = [](const int4 &a, const int4 &b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0; };
+        for (int r = 0; r < nrow; r++) {
+            const int4 qc = load_row(mine + (size_t)min(r + 2, nrow - 1) * 64);
+            int4 out = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int k = 4 * r + v;
+                if (v == 0) {
+                    if (r > 0) {
+                        outp.w = finish(fs);
+                        if (4 * (r - 1) < cnt_a && !same(outp, qprev)) mine[(size_t)(r - 1) * 64] = outp;
+                        if (r - 1 == (cnt_a >> 2)) last = outp;
+                    }
+                } else {
+                    const int ent = finish(fs);
+                    if (v == 1) out.x = ent; else if (v == 2) out.y = ent; else out.z = ent;
+                }
+                const int e0 = e1;
+                const double4 pj = p1;
+                const double mj = m1;
+                if (k + 1 < cnt_a) {
+                    e1 = v < 3 ? comp4(qa, v + 1) : qb.x;
+                    fetch(e1, true, p1, m1);
+                }
+                classify(e0, k < cnt_a, pj, mj, fs);
+            }
+            outp = out; qprev = qa;
+            qa = qb; qb = qc;
+        }
+        outp.w = finish(fs);
+        if (4 * (nrow - 1) < cnt_a && !same(outp, qprev)) mine[(size_t)(nrow - 1) * 64] = outp;
+        if (nrow - 1 == (cnt_a >> 2)) last = outp;
+    }
+    // pass 2: the margin shell, rows in ascending row index; what the new lengths switch on is appended behind the D/F
+    // entries and, where it counts for the density, summed
+    int cnt = cnt_a;
+    int4 buf = last;
+    const int rows_t = (tcnt_a + 3) >> 2;
+    const int smax = wave_max_i32(rows_t);
+    int4 qn = rows_t > 0 ? mine[(size_t)(cap4 - rows_t) * 64] : make_int4(self, self, self, self);
+    for (int s = 0; s < smax; s++) {
+        const int tr = rows_t - 1 - s;
+        const bool has = tr >= 0;
+        const int4 q = qn;
+        if (tr >= 1) qn = mine[(size_t)(cap4 - tr) * 64];
+        double4 pr[4];
+        bool on[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int e = comp4(q, v);
+            on[v] = has && 4 * tr + v < tcnt_a;
+            pr[v] = prec[on[v] ? (e & IDX_MASK) : self];
+        }
+        ReflagStage sv[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) reflag_classify(pi, li, ri2, on[v], comp4(q, v) & IDX_MASK, pr[v], lrec, orig, sv[v]);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int ent = reflag_finish(pi, oi, sv[v], number);
+            if ((uint32_t)ent & (FLAG_D | FLAG_F)) {
+                if ((uint32_t)ent & FLAG_D)
+                    density_visit_v(pim, make_double4(pr[v].x, pr[v].y, pr[v].z, mass[ent & IDX_MASK]), true, lw, ldw, inv_h, inv_dq, pc.nq, d);
+                const int q4 = cnt & 3;
+                buf.x = q4 == 0 ? ent : buf.x; buf.y = q4 == 1 ? ent : buf.y; buf.z = q4 == 2 ? ent : buf.z; buf.w = q4 == 3 ? ent : buf.w;
+                if (q4 == 3) mine[(size_t)(cnt >> 2) * 64] = buf;
+                cnt++;
+            }
+        }
+    }
+    if (cnt > cnt_a && (cnt & 3) != 0) mine[(size_t)(cnt >> 2) * 64] = buf;
+    if (i < n) ncount[i] = live ? cnt : 0;
+    const int wm = wave_max_i32(live ? cnt : 0);
+    if (lane == 0) wave_max[w] = min(wm, cap);
+    if (!live) return;
+    density_epilogue_v(pc, i, pim, hi, d, lw[0], u, alpha, vx, vy, vz, rho, omega, P, cs, frec);
+}
+
 __global__ __launch_bounds__(256) void eos_only_v_kernel(PairConst pc, int64_t n, const double4 *__restrict__ drec,
                                                          const double *__restrict__ hh, const double *__restrict__ u,
                                                          const double *__restrict__ alpha, const double *__restrict__ vx,
@@ -927,11 +1097,12 @@ int varh_h_stats(sph_ctx *c, bool with_growth) {
     h_stats_partial<<<dim3(nb), dim3(VBLOCK), 0, c->stream>>>(c->f[SPH_F_H], with_growth ? c->h_new : nullptr, n, part);
     h_stats_final<<<dim3(1), dim3(64), 0, c->stream>>>(part, nb, part + 2048);
     VH_CHECK(hipGetLastError());
-    VH_CHECK(hipMemcpyAsync(c->h_pinned + 28, part + 2048, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VH_CHECK(hipMemcpyAsync(c->h_pinned + 28, part + 2048, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     VH_CHECK(hipStreamSynchronize(c->stream));
     c->h_max_glob = c->h_pinned[28];
     c->h_mean = c->h_pinned[29] / (double)n;
-    if (with_growth) c->h_growth = c->h_pinned[30];
+    c->h_shrink = INFINITY;
+    if (with_growth) { c->h_growth = c->h_pinned[30]; c->h_shrink = c->h_pinned[31]; }
     if (!(c->h_max_glob > 0.0) || !std::isfinite(c->h_max_glob)) { c->err = "variable h: non-positive or non-finite smoothing length"; return SPH_ERR_ARG; }
     return SPH_OK;
 }
@@ -1000,13 +1171,13 @@ int varh_nlist_build(sph_ctx *c) {
     const unsigned gb = (unsigned)((n + VBLOCK - 1) / VBLOCK);
     const double grow = no_reflag ? 1.0 : REFLAG_GROW;
     for (int attempt = 0; attempt < 8; attempt++) {
-        VH_CHECK(hipMemsetAsync(c->d_flags + 1, 0, sizeof(int32_t), c->stream));
+        // per-wave row needs go to wave_class (free in variable-h mode: no split force evaluation), their maximum straight to the host
         nlist_v_tiled<<<dim3(gb), dim3(VBLOCK), 0, c->stream>>>(
             c->grid, R, c->h_max_glob, grow * grow, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), c->orig,
-            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->d_flags,
+            c->cell_start, c->cell_hmax, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max, c->wave_class,
             c->numbers_set ? c->number : nullptr);
+        max_to_host<<<dim3(1), dim3(1024), 0, c->stream>>>(c->wave_class, (n + 63) / 64, reinterpret_cast<int32_t *>(c->h_pinned + 9));
         VH_CHECK(hipGetLastError());
-        VH_CHECK(hipMemcpyAsync(c->h_pinned + 9, c->d_flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         VH_CHECK(hipStreamSynchronize(c->stream));
         const int32_t mx = *reinterpret_cast<int32_t *>(c->h_pinned + 9);
         c->nl_max = mx;
@@ -1040,6 +1211,22 @@ int varh_nlist_reflag(sph_ctx *c) {
         c->nlist, c->ncount, c->ntail, c->wave_max, c->numbers_set ? c->number : nullptr);
     VH_CHECK(hipGetLastError());
     c->list_has_margin = false;        // the margin rows may be overwritten: calc_smoothing falls back to its cell walk on this list
+    c->nlist_reflags++;
+    return SPH_OK;
+}
+
+// the re-flag pass and the start-of-step density pass in one kernel (reflag_density_kernel); as varh_nlist_reflag otherwise
+int varh_reflag_density(sph_ctx *c, const PairConst &pc) {
+    const int64_t n = c->n;
+    if (n == 0) return SPH_OK;
+    const size_t lds = (size_t)(pc.nq + 1) * 2 * sizeof(double);
+    reflag_density_kernel<<<dim3((unsigned)((n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
+        pc, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), reinterpret_cast<const double4 *>(c->drec),
+        c->f[SPH_F_M], c->orig, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max,
+        c->numbers_set ? c->number : nullptr, c->w_tab, c->dw_tab, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY],
+        c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_OMEGA], c->f[SPH_F_P], c->f[SPH_F_C], c->frec);
+    VH_CHECK(hipGetLastError());
+    c->list_has_margin = false;
     c->nlist_reflags++;
     return SPH_OK;
 }

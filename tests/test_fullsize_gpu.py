@@ -141,6 +141,105 @@ def test_variable_h_momentum_at_full_size(capi):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] at its full size against the CPU oracle evaluating THE SAME 1e6 particles (its own octree leaf boxes)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def var_disc():
+    return ic.split_rows(ic.keplerian_disc_var(N, seed=303))        # the bench's variable-h workload
+
+
+def _per_element(got, ref, idx, tol, floor=0.0):
+    """every sampled element within tol of ITS OWN value (where that value is not a cancellation residue: |ref| > floor)"""
+    g, r = got[idx], ref[idx]
+    ok = np.abs(r) > floor
+    return float(np.max(np.abs(g[ok] - r[ok]) / np.abs(r[ok]))) <= tol
+
+
+def test_variable_h_full_size_vs_oracle(capi, var_disc):
+    """rho, Omega, the rates and the updated h of the 1e6-particle variable-h disc: against oracle/sph_oracle_v.c on the same
+    particles -- field-wise <= 1e-13 of the field's scale for ALL particles, and element-wise for 4000 random targets (rho,
+    Omega, du <= 1e-12 of their own value; the leaf-box rule decides membership, so one wrong neighbour shows at 1e-2)"""
+    from oracle import orc, orc_v
+    gas, sinks = var_disc
+    ctx = capi.Context(device=0, variable=True)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    o = orc_v.OracleV(gas, sinks, nthreads=orc.max_threads())
+    ctx.density(); ctx.forces(); o.evaluate()
+    idx = np.random.default_rng(5).choice(N, 4000, replace=False)
+    for f in ("rho", "omega", "ax", "ay", "az", "du", "dalpha"):
+        got, ref = ctx.field(f), getattr(o, f)
+        assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)), f
+    assert _per_element(ctx.field("rho"), o.rho, idx, 1e-12)
+    assert _per_element(ctx.field("omega"), o.omega, idx, 1e-12)
+    du_scale = float(np.max(np.abs(o.du)))
+    assert _per_element(ctx.field("du"), o.du, idx, 1e-9, floor=1e-4 * du_scale)
+    assert ctx.next_dt(1e-2) == o.next_dt(1e-2)
+    ctx.update_h(); o.update_h()
+    assert np.max(np.abs(ctx.field("h") - o.h)) <= 1e-12 * np.max(o.h)
+    ctx.close()
+
+
+def test_variable_h_reflag_path_at_full_size(capi, var_disc):
+    """12 steps of the 1e6 disc through the re-flag pass (the default) and with SPH_FLAG_NO_REFLAG (every list built): identical
+    dt decisions, state equal to rounding -- and the density the re-flagged list gives at the start of step 13 against the
+    oracle evaluating the same 1e6 particles with the same h (element-wise for 4000 targets)"""
+    from oracle import orc, orc_v
+    gas, sinks = var_disc
+    runs = {}
+    for tag, flags in (("reflag", 0), ("build", capi.FLAG_NO_REFLAG)):
+        ctx = capi.Context(device=0, variable=True, flags=capi.FLAG_VARIABLE_H | flags)
+        ctx.upload(gas); ctx.set_sinks(sinks)
+        dts, t = [1e-2], 0.0
+        for _ in range(12):
+            dt, t = ctx.run(1, dts[-1], t)
+            dts.append(dt)
+        st = ctx.stats()
+        runs[tag] = dict(dts=dts, reflags=st.nlist_reflags, ctx=ctx, **{f: ctx.field(f) for f in "x y z vx u h alpha".split()})
+    assert runs["reflag"]["dts"] == runs["build"]["dts"]
+    assert runs["reflag"]["reflags"] >= 6 and runs["build"]["reflags"] == 0
+    for f in "x y z vx u h alpha".split():
+        a, b = runs["reflag"][f], runs["build"][f]
+        assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b)), f
+    runs["build"]["ctx"].close()
+    # start of step 13: the h of calc_smoothing is newer than the list -> the short path re-flags; its rho vs the oracle
+    ctx = runs["reflag"]["ctx"]
+    before = ctx.stats().nlist_reflags
+    ctx.density()
+    assert ctx.stats().nlist_reflags == before + 1
+    state = {k: ctx.field(k) for k in "x y z vx vy vz u m alpha h".split()}
+    o = orc_v.OracleV(state, sinks, nthreads=orc.max_threads())
+    o.density()
+    idx = np.random.default_rng(6).choice(N, 4000, replace=False)
+    assert np.max(np.abs(ctx.field("rho") - o.rho)) <= 1e-13 * np.max(o.rho)
+    assert _per_element(ctx.field("rho"), o.rho, idx, 1e-12) and _per_element(ctx.field("omega"), o.omega, idx, 1e-12)
+    ctx.close()
+
+
+@pytest.mark.timeout(600)
+def test_variable_h_reflag_soak_200_steps(capi):
+    """1e5 particles, 200 steps with and without the re-flag pass (promoted from tests/tools/reflag_long_run.py): the neighbour
+    sets stay those of a build all the way -- identical dt decisions, state equal to rounding"""
+    n, steps = 100_000, 200
+    gas, sinks = ic.split_rows(ic.keplerian_disc_var(n, seed=71))
+    out = {}
+    for tag, flags in (("build", capi.FLAG_NO_REFLAG), ("reflag", 0)):
+        ctx = capi.Context(device=0, variable=True, flags=capi.FLAG_VARIABLE_H | flags)
+        ctx.upload(gas); ctx.set_sinks(sinks)
+        dts, t = [1e-2], 0.0
+        for _ in range(steps):
+            dt, t = ctx.run(1, dts[-1], t)
+            dts.append(dt)
+        st = ctx.stats()
+        out[tag] = dict(dts=dts, reflags=st.nlist_reflags, **{f: ctx.field(f) for f in "x vx u h rho alpha".split()})
+        ctx.close()
+    assert out["build"]["dts"] == out["reflag"]["dts"]
+    assert out["reflag"]["reflags"] >= 150 and out["build"]["reflags"] == 0
+    for f in "x vx u h rho alpha".split():
+        a, b = out["build"][f], out["reflag"][f]
+        assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(a)), f
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3] at its full size: thin ring, 4e6 particles, artificial viscosity at work
 # ------------------------------------------------------------------------------------------------------------------
 N_RING = 4_000_000
