@@ -172,10 +172,11 @@ void resolve_timing(sph_ctx *c) {
 // The whole-tile kernels are persistent, one workgroup per CU.  density_wt walks over groups of 1024 targets: with fewer groups
 // than CUs it leaves CUs idle, and below ~0.75 groups per CU the gather kernel of pairs.hip (a workgroup per 256 targets) is
 // faster -- measured on MI355X (tests/tools/small_n_ab.sh, ms per pass): 12 000 particles 0.032 vs 0.069, 100 000: 0.048 vs
-// 0.071, 300 000 (293 groups): 0.098 vs 0.077 for the tile kernel.  forces_q (groups of 256, four lanes per target) wins at every
+// 0.071, 300 000 (293 groups): 0.098 vs 0.077 for the tile kernel; 200 000 particles with ~200 neighbours each (196 groups,
+// table-free tile): 0.205 vs 0.358 -- hence one group per CU at least.  forces_q (groups of 256, four lanes per target) wins at every
 // size, 47 groups included (12 000 particles: 0.032 vs 0.049 ms).  SPH_TILE_MIN_GROUPS_D / _F: A/B switches (x0.01 groups per CU).
 bool use_tile_kernel(const sph_ctx *c, bool forces) {
-    static const int thr_d = getenv("SPH_TILE_MIN_GROUPS_D") ? atoi(getenv("SPH_TILE_MIN_GROUPS_D")) : 75;
+    static const int thr_d = getenv("SPH_TILE_MIN_GROUPS_D") ? atoi(getenv("SPH_TILE_MIN_GROUPS_D")) : 100;
     static const int thr_f = getenv("SPH_TILE_MIN_GROUPS_F") ? atoi(getenv("SPH_TILE_MIN_GROUPS_F")) : 0;
     if (!c->whole_tile || !(forces ? c->wt_ok_f : c->wt_ok)) return false;
     const int64_t groups = (c->n + (forces ? 255 : 1023)) / (forces ? 256 : 1024);

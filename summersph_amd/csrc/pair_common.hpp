@@ -97,6 +97,36 @@ __device__ __forceinline__ double table_lerp(const double *__restrict__ tab, dou
     return fma(a, tab[k + 1], (1.0 - a) * tab[k]);
 }
 
+// The table values themselves, recomputed: knot k of the W / dW table exactly as host_tables (api.hip, [F]:55-79) fills it --
+// q = k dq, the same expressions under contract(off), so bitwise the table's values.  The whole-tile kernels use this when
+// the 40-KB table would not leave the tile enough LDS (dense neighbourhoods): ~12 vector instructions per knot instead of an
+// LDS read, which is still far cheaper than falling back to the direct gathers.
+__device__ __forceinline__ double w_knot(int k, double dq) {
+#pragma clang fp contract(off)
+    const double q = k * dq;
+    const double t = 2.0 - q;
+    const double a = 1.0 - 1.5 * (q * q) + 0.75 * (q * q * q);
+    const double b = 0.25 * (t * t * t);
+    return (q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0);
+}
+__device__ __forceinline__ double dw_knot(int k, double dq) {
+#pragma clang fp contract(off)
+    const double q = k * dq;
+    const double t = 2.0 - q;
+    const double a = -3.0 * q + 2.25 * (q * q);
+    const double b = -0.75 * (t * t);
+    return (q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0);
+}
+// lookup_kernel's interpolation with a knot function instead of a table in memory
+template <class KnotFn>
+__device__ __forceinline__ double knot_lerp(KnotFn knot, double qi, double inv_dq, int nq) {
+#pragma clang fp contract(off)
+    const double t = qi * inv_dq;
+    const int k = min((int)t, nq - 1);
+    const double a = t - (double)k;
+    return fma(a, knot(k + 1), (1.0 - a) * knot(k));
+}
+
 // both tables at once (same knot, same weight)
 __device__ __forceinline__ void table_lerp2(const double *__restrict__ tw, const double *__restrict__ tdw, double qi,
                                             double inv_dq, int nq, double &w, double &dw) {
@@ -121,8 +151,9 @@ __device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i,
 }
 
 // one visit of the density sum, [F]:443-455: acc += m_j w(q_ij) (un-normalised, [F]:125 is applied once at the end)
-__device__ __forceinline__ void density_visit(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lds_w,
-                                              double inv_h, double inv_dq, int nq, double &acc) {
+// w_of(q): the interpolated, un-normalised W table value (table_lerp on a table in LDS, or knot_lerp)
+template <class WFn>
+__device__ __forceinline__ void density_visit_fn(const double4 &pi, const double4 &pj, bool act, WFn w_of, double inv_h, double &acc) {
 #pragma clang fp contract(off)
     const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
     double dr, rs;
@@ -131,7 +162,11 @@ __device__ __forceinline__ void density_visit(const double4 &pi, const double4 &
     // no control flow: a lane that does not count ([F]:113: q > 2; idle lanes) adds an exact zero, and consecutive visits
     // can overlap
     const double mj = (act && qi <= 2.0) ? pj.w : 0.0;
-    acc = fma(mj, table_lerp(lds_w, fmin(qi, 2.0), inv_dq, nq), acc);      // [F]:114-118,454
+    acc = fma(mj, w_of(fmin(qi, 2.0)), acc);                               // [F]:114-118,454
+}
+__device__ __forceinline__ void density_visit(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lds_w,
+                                              double inv_h, double inv_dq, int nq, double &acc) {
+    density_visit_fn(pi, pj, act, [&](double q) { return table_lerp(lds_w, q, inv_dq, nq); }, inv_h, acc);
 }
 
 // self term, normalisation, EOS and the force record of particle i ([F]:443-455 visits the particle's own leaf: r = 0;

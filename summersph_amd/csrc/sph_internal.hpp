@@ -95,6 +95,7 @@ struct sph_ctx {
     bool tiled = true;               // fixed-h: LDS-staged neighbour-list build (tiled.hip) unless SPH_FLAG_NO_LDS_TILES
     bool whole_tile = false;         // fixed-h: density/forces read the neighbours' {x,y,z,m} from one LDS tile per workgroup (tiled.hip)
     bool wt_ok = false, wt_ok_f = false;   // ... and the last list build found that the workgroups' intervals fit the tile (density / forces geometry)
+    bool wt_big = false, wt_big_f = false; // ... only the table-free tile (the kernel table's knots recomputed, 40 KB more for the tile)
     int32_t wt_fit_pct = -1, wt_fit_pct_f = -1;   // percentage of workgroups that fit (-1: kernels off)
     bool packed_list = true;         // list layout: 4-packed (tiled build) or wave-strided dwords (nlist_kernel)
     double *prec = nullptr;          // 4 doubles: x y z h        (neighbour-list build)

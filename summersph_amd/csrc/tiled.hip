@@ -224,7 +224,9 @@ __device__ __forceinline__ void tile_map(const GridDesc &g, const int32_t *__res
     m.need = total;
 }
 
-template <int BS>
+// TAB: the W table sits in LDS beside the tile (the default); !TAB: its knots are recomputed (w_knot, bitwise the table's values)
+// and the tile gets the table's 40 KB -- for neighbourhoods so dense that the three intervals of a group do not fit otherwise
+template <int BS, bool TAB>
 __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
                                                  const int32_t *__restrict__ plan_f,
                                                  const double4 *__restrict__ drec, const int32_t *__restrict__ nlist,
@@ -237,14 +239,17 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                                                  double *__restrict__ frec, const int32_t *__restrict__ orig, int32_t n_owned) {
     extern __shared__ double lds_dyn[];
     double *lds_w = lds_dyn;                                               // nq+1 doubles (padded to even)
-    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + ((pc.nq + 2) & ~1));
+    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TAB ? ((pc.nq + 2) & ~1) : 0));
     // persistent, as forces_q: one workgroup per CU walks over groups of BS targets; the table once, the plan one group ahead;
     // XCD x works on one contiguous eighth of the groups (its L2 then holds what neighbouring groups stage twice)
-    for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_w[k] = w_tab[k];
+    if (TAB) for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_w[k] = w_tab[k];
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const int lane = threadIdx.x & 63;
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    auto w_of = [&](double q) {
+        return TAB ? table_lerp(lds_w, q, inv_dq, pc.nq) : knot_lerp([&](int k) { return w_knot(k, pc.dq); }, q, inv_dq, pc.nq);
+    };
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
     if (group < g_hi) load_plan(plan, group, tm_next);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                         const int k = 8 * r + 4 * hh + v;     // longest list are masked like any idle lane
                         const double4 pj = p1;
                         p1 = tile[k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : 0];
-                        density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                        density_visit_fn(pi, pj, k < cnt, w_of, inv_h, acc);
                     }
                 }
                 qa = qb; qb = qc;
@@ -312,13 +317,13 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                         const int k = 8 * r + 4 * hh + v;
                         const double4 pj = p1;
                         if (k + 1 < cnt) p1 = drec[em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt)];
-                        density_visit(pi, pj, k < cnt, lds_w, inv_h, inv_dq, pc.nq, acc);
+                        density_visit_fn(pi, pj, k < cnt, w_of, inv_h, acc);
                     }
                 }
                 qa = qb; qb = qc;
             }
         }
-        if (live) density_epilogue(pc, i, pi, acc, lds_w[0], u, alpha, vx, vy, vz, rho, P, cs, frec);
+        if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq), u, alpha, vx, vy, vz, rho, P, cs, frec);
     }
 }
 
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
 // eight records spreads a wave's scattered 16-byte reads over all banks (6 s mod 16 alone hits the even units only).  The LPT partial sums of a target are added in a fixed tree (lane order), so results are reproducible;
 // they differ from the one-lane kernels' by summation order (parity tolerance, not bitwise).
 
-template <int BS, int LPT>
+template <int BS, int LPT, bool TAB>
 __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32_t ngroups, const int32_t *__restrict__ plan,
                                                const int2 *__restrict__ deal,
                                                const double *__restrict__ frec, const int32_t *__restrict__ nlist,
@@ -347,20 +352,24 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     constexpr int T = BS / LPT;
     extern __shared__ double lds_dyn[];
     double *lds_dw = lds_dyn;
-    double2 *tile = reinterpret_cast<double2 *>(lds_dyn + ((pc.nq + 2) & ~1));
+    double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? ((pc.nq + 2) & ~1) : 0));      // !TAB: dW knots recomputed (density_wt)
     __shared__ int s_tgt[T];
     const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x >> 2;
     const double4 *fg = reinterpret_cast<const double4 *>(frec);
     // the dw table once per workgroup: the kernel is persistent, one workgroup per CU walks over many groups of T targets
-    for (int t = threadIdx.x; t < ((pc.nq + 1) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
-    if (threadIdx.x == 0 && ((pc.nq + 1) & 1)) lds_dw[pc.nq] = dw_tab[pc.nq];
+    if (TAB) {
+        for (int t = threadIdx.x; t < ((pc.nq + 1) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
+        if (threadIdx.x == 0 && ((pc.nq + 1) & 1)) lds_dw[pc.nq] = dw_tab[pc.nq];
+    }
     // workgroups b, b + 8, .. share an XCD (round-robin dispatch, speed only): XCD x works on one contiguous eighth of the
     // groups, so that the up to nine workgroups that stage a record find it in that XCD's L2; its workgroups take the
     // groups of that eighth in turn
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
-    auto dw_of = [&](double q) { return table_lerp(lds_dw, q, inv_dq, pc.nq); };
+    auto dw_of = [&](double q) {
+        return TAB ? table_lerp(lds_dw, q, inv_dq, pc.nq) : knot_lerp([&](int k) { return dw_knot(k, pc.dq); }, q, inv_dq, pc.nq);
+    };
     // what does not need the tile is fetched one group ahead: the plan and the dealt target of this thread
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
@@ -478,11 +487,12 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
 // (Computing the intervals inside the evaluation kernels cost them 18 dependent cell-table reads per thread, two wave
 // reductions and a barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
 __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, int64_t ngroups_f, const int32_t *__restrict__ plan_f, int32_t tcap_d,
-                                                           int32_t tcap_f, int32_t *__restrict__ plan_d, int32_t *__restrict__ report) {
+                                                           int32_t tcap_f, int32_t tcap_d_big, int32_t tcap_f_big, int32_t *__restrict__ plan_d,
+                                                           int32_t *__restrict__ report) {
     // ONE workgroup strides over the density groups (977 at 1e6 particles) and writes the four numbers straight into the host's
     // report slot (pinned memory mapped into the device's address space): no atomics, no device-to-host copy kernels
-    __shared__ int s_red[4][16];
-    int mx_list = 0, mx_need = 0, misfit_f = 0, misfit_d = 0;
+    __shared__ int s_red[6][16];
+    int mx_list = 0, mx_need = 0, misfit_f = 0, misfit_d = 0, misfit_fb = 0, misfit_db = 0;      // ..b: against the table-free (bigger) tiles
     for (int64_t gd = threadIdx.x; gd < ngroups_d; gd += 1024) {
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
         for (int64_t gf = 4 * gd; gf < std::min<int64_t>(4 * gd + 4, ngroups_f); gf++) {
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, in
                 if (len[q] > 0) { lo[q] = min(lo[q], l[q]); hi[q] = max(hi[q], l[q] + len[q]); }
             mx_need = max(mx_need, b.z); mx_list = max(mx_list, b.w);
             misfit_f += b.z > tcap_f ? 1 : 0;
+            misfit_fb += b.z > tcap_f_big ? 1 : 0;
         }
         if (plan_d) {
             int need = 0;
@@ -503,21 +514,24 @@ __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, in
             }
             p[6] = need; p[7] = 0;
             misfit_d += need > tcap_d ? 1 : 0;
+            misfit_db += need > tcap_d_big ? 1 : 0;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
         mx_list = max(mx_list, __shfl_xor(mx_list, o, 64)); mx_need = max(mx_need, __shfl_xor(mx_need, o, 64));
         misfit_f += __shfl_xor(misfit_f, o, 64); misfit_d += __shfl_xor(misfit_d, o, 64);
+        misfit_fb += __shfl_xor(misfit_fb, o, 64); misfit_db += __shfl_xor(misfit_db, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         const int wv = threadIdx.x >> 6;
-        s_red[0][wv] = mx_list; s_red[1][wv] = misfit_d; s_red[2][wv] = misfit_f; s_red[3][wv] = mx_need;
+        s_red[0][wv] = mx_list; s_red[1][wv] = misfit_d; s_red[2][wv] = misfit_f; s_red[3][wv] = mx_need; s_red[4][wv] = misfit_db; s_red[5][wv] = misfit_fb;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        for (int k = 0; k < 16; k++) { r0 = max(r0, s_red[0][k]); r1 += s_red[1][k]; r2 += s_red[2][k]; r3 = max(r3, s_red[3][k]); }
-        report[0] = r0; report[1] = r1; report[2] = r2; report[3] = r3;      // {longest list, misfits density, misfits forces, largest need}
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
+        for (int k = 0; k < 16; k++) { r0 = max(r0, s_red[0][k]); r1 += s_red[1][k]; r2 += s_red[2][k]; r3 = max(r3, s_red[3][k]); r4 += s_red[4][k]; r5 += s_red[5][k]; }
+        // {longest list, misfits density, misfits forces, largest need, misfits density / forces with the table-free tiles}
+        report[0] = r0; report[1] = r1; report[2] = r2; report[3] = r3; report[4] = r4; report[5] = r5;
     }
 }
 
@@ -532,8 +546,8 @@ int32_t tile_cap(int nq, int rec, bool tablds) {
 }
 
 // forces_q: 6 units of 16 bytes per record + 1 per eight records
-int32_t tile_cap_q(int nq) {
-    const size_t tab = (size_t)((nq + 2) & ~1) * sizeof(double);
+int32_t tile_cap_q(int nq, bool tablds = true) {
+    const size_t tab = tablds ? (size_t)((nq + 2) & ~1) * sizeof(double) : 0;
     constexpr size_t reserve = 4096;            // static LDS of forces_q
     if (tab + reserve + 64 >= (size_t)LDS_BYTES) return 0;
     const size_t units = ((size_t)LDS_BYTES - reserve - tab) / 16 - 2;
@@ -579,10 +593,17 @@ int nlist_build_tiled(sph_ctx *c) {
         if (c->whole_tile) {
             // the whole-tile kernels pay a prologue and run their fall-back loop at one workgroup per CU: use them when
             // (nearly) every workgroup's intervals fit the tile -- thin discs and sheets; thick domains keep pairs.hip
-            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)rep[1]) / std::max<int64_t>(d_blocks, 1));
-            c->wt_ok = (int64_t)rep[1] * 10 <= (int64_t)d_blocks;
-            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[2]) / std::max<int64_t>(f_blocks, 1));
-            c->wt_ok_f = (int64_t)rep[2] * 10 <= (int64_t)f_blocks;
+            // ... with the kernel table beside the tile; where that fails but the table-free tile (40 KB larger, knots recomputed)
+            // holds the intervals -- dense neighbourhoods -- the table-free variant runs (SPH_TILE_TABLE=regs: always, A/B)
+            static const bool force_big = getenv("SPH_TILE_TABLE") && std::string(getenv("SPH_TILE_TABLE")) == "regs";
+            const bool ok_d = (int64_t)rep[1] * 10 <= (int64_t)d_blocks, ok_db = (int64_t)rep[4] * 10 <= (int64_t)d_blocks;
+            const bool ok_f = (int64_t)rep[2] * 10 <= (int64_t)f_blocks, ok_fb = (int64_t)rep[5] * 10 <= (int64_t)f_blocks;
+            c->wt_big = force_big || (!ok_d && ok_db);
+            c->wt_big_f = force_big || (!ok_f && ok_fb);
+            c->wt_ok = c->wt_big ? ok_db : ok_d;
+            c->wt_ok_f = c->wt_big_f ? ok_fb : ok_f;
+            c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big ? 4 : 1]) / std::max<int64_t>(d_blocks, 1));
+            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big_f ? 5 : 2]) / std::max<int64_t>(f_blocks, 1));
         }
     };
     // Steady state: the report of the PREVIOUS build (it arrived long ago) is read instead of waiting for this one's.  The
@@ -612,6 +633,7 @@ int nlist_build_tiled(sph_ctx *c) {
             const int64_t ngd = (n + WT_BS - 1) / WT_BS, ngf = (n + FQ_T - 1) / FQ_T;
             plan_reduce_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(
                 ngd, ngf, c->plan_f, c->whole_tile ? tile_cap(pc.nq, 4, true) : 0, c->whole_tile ? tile_cap_q(pc.nq) : LIST16_MAX_NEED,
+                c->whole_tile ? tile_cap(pc.nq, 4, false) : 0, c->whole_tile ? tile_cap_q(pc.nq, false) : LIST16_MAX_NEED,
                 c->whole_tile ? c->plan_d : nullptr, slot);
             TL_CHECK(hipGetLastError());
         }
@@ -655,31 +677,37 @@ static unsigned persistent_grid(const sph_ctx *c, int64_t ngroups) {
     return (unsigned)std::min<int64_t>(ngroups, cus);
 }
 
-hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
-    if (c->n == 0) return hipSuccess;
-    const int32_t tcap = tile_cap(pc.nq, 4, true);
-    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + (size_t)tcap * sizeof(double4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <bool TAB>
+static hipError_t density_wt_launch(sph_ctx *c, const PairConst &pc) {
+    const int32_t tcap = tile_cap(pc.nq, 4, TAB);
+    const size_t lds = (TAB ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)tcap * sizeof(double4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
     const unsigned grid = persistent_grid(c, ngroups);
-    density_wt<WT_BS><<<dim3(grid), dim3(WT_BS), lds, c->stream>>>(
+    density_wt<WT_BS, TAB><<<dim3(grid), dim3(WT_BS), lds, c->stream>>>(
         pc, tcap, (int32_t)ngroups, c->plan_d, c->plan_f, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max,
         c->w_tab, c->n, c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX],
         c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO], c->f[SPH_F_P], c->f[SPH_F_C], c->frec, c->orig, (int32_t)c->n_owned);
     return hipGetLastError();
 }
 
+hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
+    if (c->n == 0) return hipSuccess;
+    return c->wt_big ? density_wt_launch<false>(c, pc) : density_wt_launch<true>(c, pc);
+}
+
+template <bool TAB>
 static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     constexpr int BS = 1024, LPT = 4;
-    const int32_t tcap = tile_cap_q(pc.nq);
-    const size_t lds = (size_t)((pc.nq + 2) & ~1) * sizeof(double) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int32_t tcap = tile_cap_q(pc.nq, TAB);
+    const size_t lds = (TAB ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     constexpr int T = BS / LPT;
     const int64_t ngroups = (c->n + T - 1) / T;
     const unsigned grid = persistent_grid(c, ngroups);
-    forces_q<BS, LPT><<<dim3(grid), dim3(BS), lds, c->stream>>>(
+    forces_q<BS, LPT, TAB><<<dim3(grid), dim3(BS), lds, c->stream>>>(
         pc, tcap, (int32_t)ngroups, c->plan_f, reinterpret_cast<const int2 *>(c->deal), c->frec, c->nlist, c->nl_cap, c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
         part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
@@ -689,7 +717,7 @@ static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
 // part 0: every wave.  part 1 / 2: only the waves of class 0 (interior) / class 1, as launch_forces
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
-    return forces_q_launch(c, pc, part);
+    return c->wt_big_f ? forces_q_launch<false>(c, pc, part) : forces_q_launch<true>(c, pc, part);
 }
 
 }  // namespace sph

@@ -89,12 +89,12 @@ def test_ragged_size_and_trajectory(capi):
 
 
 def test_thick_domain_keeps_the_gather_kernels(capi):
-    # a cube of 40^3 cells' worth of particles: the three intervals of a workgroup span whole columns, nothing fits
+    # a cube 36 cells high: the three intervals of a workgroup span whole columns, nothing fits (not even the table-free tile)
     rng = np.random.default_rng(8)
-    n = 150_000
+    n = 450_000
     gas = {k: np.zeros(n) for k in "x y z vx vy vz u m alpha".split()}
     for k in "xyz":
-        gas[k] = rng.uniform(0.0, 120.0, n)
+        gas[k] = rng.uniform(0.0, 180.0, n)
     gas["u"][:] = 0.25; gas["m"][:] = 1e-4; gas["alpha"][:] = 0.1
     gas["vx"] = rng.normal(0.0, 0.05, n)
     sinks = {k: np.zeros(0) for k in "x y z vx vy vz m".split()}
@@ -149,3 +149,51 @@ def test_counting_sort_gives_the_order_of_the_stable_radix_sort(tmp_path):
         out[tag] = dict(np.load(path))
     for f in out["count"]:
         assert np.array_equal(out["count"][f], out["radix"][f]), f
+
+
+def test_table_free_tile_kernels_are_bitwise_the_table_kernels(tmp_path):
+    """dense neighbourhoods get the tile kernels with the kernel table's knots RECOMPUTED (w_knot / dw_knot: the table's 40 KB
+    go to the tile).  SPH_TILE_TABLE=regs (read once per process) forces that variant on an ordinary disc: every field must
+    equal the table variant's bit for bit -- the knots are the table's values, the operations and their order the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from summersph_amd import capi, ic\n"
+        "gas, sinks = ic.split_rows(ic.keplerian_disc(120_000, seed=19, nngb=85.0))\n"
+        "rng = np.random.default_rng(4); gas['vx'] = gas['vx'] + rng.normal(0.0, 0.05, gas['x'].size); gas['alpha'] = np.full(gas['x'].size, 0.3)\n"
+        "ctx = capi.Context(device=0)\n"
+        "ctx.upload(gas); ctx.set_sinks(sinks)\n"
+        "ctx.density(); ctx.forces()\n"
+        "st = ctx.stats()\n"
+        "assert st.tile_fit_pct >= 90 and st.tile_fit_pct_forces >= 90\n"
+        "ev = {f: ctx.field(f) for f in 'rho P c ax ay az du dalpha'.split()}\n"
+        "ctx.run(3, 1e-2, 0.0)\n"
+        "np.savez(sys.argv[1], **ev, **{'t_' + f: ctx.field(f) for f in 'x vx u alpha'.split()})\n"
+    )
+    out = {}
+    # SPH_TILE_MIN_GROUPS_D=0: the tile kernel also for the density pass of this small set (fewer groups than CUs)
+    for tag, env in (("table", {"SPH_TILE_MIN_GROUPS_D": "0"}), ("regs", {"SPH_TILE_TABLE": "regs", "SPH_TILE_MIN_GROUPS_D": "0"})):
+        path = tmp_path / f"{tag}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env={**os.environ, **env}, timeout=300)
+        out[tag] = dict(np.load(path))
+    for f in out["table"]:
+        assert np.array_equal(out["table"][f], out["regs"][f]), f
+
+
+def test_dense_disc_runs_from_the_table_free_tiles(capi):
+    """~200 neighbours (the survey's anchor regime): the three intervals of a group no longer fit beside the 40-KB table, but
+    they fit the table-free tile -- the context must pick it, and agree with the direct-gather kernels as the table variant does"""
+    gas, sinks = ic.split_rows(ic.keplerian_disc(100_000, seed=212, nngb=340.0))
+    rng = np.random.default_rng(3)
+    gas["vx"] = gas["vx"] + rng.normal(0.0, 0.05, gas["x"].size)
+    gas["alpha"] = np.full(gas["x"].size, 0.3)
+    a, sa = evaluate(capi, gas, sinks, 0)
+    b, _ = evaluate(capi, gas, sinks, capi.FLAG_NO_WHOLE_TILE)
+    assert sa.nlist_mean > 150
+    assert sa.tile_fit_pct >= 90, (sa.tile_fit_pct, sa.tile_fit_pct_forces)      # the density geometry fits the table-free tile
+    for f in FIELDS:
+        assert same(a[f], b[f], f), f
