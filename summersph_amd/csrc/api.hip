@@ -43,7 +43,7 @@ void free_particle_arrays(sph_ctx *c) {
     ctx_free(c, c->keys); ctx_free(c, c->keys_alt); ctx_free(c, c->vals); ctx_free(c, c->vals_alt);
     ctx_free(c, c->sort_tmp);
     ctx_free(c, c->nlist); ctx_free(c, c->ncount); ctx_free(c, c->wave_max); ctx_free(c, c->ntail); ctx_free(c, c->wave_class); ctx_free(c, c->leaf_half);
-    ctx_free(c, c->plan_d); ctx_free(c, c->plan_f); ctx_free(c, c->deal);
+    ctx_free(c, c->plan_d); ctx_free(c, c->plan_f); ctx_free(c, c->plan_h); ctx_free(c, c->deal);
     for (auto &g : c->g_cache) ctx_free(c, g);
     c->grav_valid = false;
     ctx_free(c, c->sel_ids); c->sel_cap = 0;
@@ -84,6 +84,7 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
     API_TRY(ctx_alloc(c, &c->wave_class, (size_t)c->nl_waves_cap, "wave classes"));
     API_TRY(ctx_alloc(c, &c->plan_d, (size_t)(cap / 256 + 2) * 8, "tile plans (density)"));
     API_TRY(ctx_alloc(c, &c->plan_f, (size_t)(cap / 256 + 2) * 8, "tile plans (forces)"));
+    API_TRY(ctx_alloc(c, &c->plan_h, (size_t)(cap / 256 + 2) * 16, "tile plans (forces, half groups)"));
     API_TRY(ctx_alloc(c, &c->deal, 2 * ((size_t)cap + 256), "dealing order"));
     if (c->variable) {
         API_TRY(ctx_alloc(c, &c->prec, (size_t)cap * 4, "position+h records"));

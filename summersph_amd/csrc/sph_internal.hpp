@@ -95,6 +95,7 @@ struct sph_ctx {
     bool tiled = true;               // fixed-h: LDS-staged neighbour-list build (tiled.hip) unless SPH_FLAG_NO_LDS_TILES
     bool whole_tile = false;         // fixed-h: density/forces read the neighbours' {x,y,z,m} from one LDS tile per workgroup (tiled.hip)
     bool wt_ok = false, wt_ok_f = false;   // ... and the last list build found that the workgroups' intervals fit the tile (density / forces geometry)
+    bool wt_half_f = false;                // forces_q on groups of 128 targets (eight lanes each): half the tile need of a group of 256
     bool wt_big = false, wt_big_f = false; // ... only the table-free tile (the kernel table's knots recomputed, 40 KB more for the tile)
     int32_t wt_fit_pct = -1, wt_fit_pct_f = -1;   // percentage of workgroups that fit (-1: kernels off)
     bool packed_list = true;         // list layout: 4-packed (tiled build) or wave-strided dwords (nlist_kernel)
@@ -161,6 +162,7 @@ struct sph_ctx {
     // nlist[(w*nl_cap + k)*64 + lane]  -> a wave reads 64 consecutive ints per k
     int32_t *nlist = nullptr; int32_t nl_cap = 0; int64_t nl_waves_cap = 0;
     int32_t *ncount = nullptr; int32_t *wave_max = nullptr;
+    int32_t *plan_h = nullptr;                      // ... and of every half group (128 targets) of forces_q
     int32_t *plan_d = nullptr, *plan_f = nullptr;   // whole-tile kernels: the tile intervals of every workgroup (density / forces geometry), per list build
     int32_t *deal = nullptr;                        // forces_q: order of the targets within their workgroup (by list length)
     int32_t *ntail = nullptr;        // variable h: entries of the margin shell, stored from the end of the lane's column

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
                                                   int4 *__restrict__ nlist4, int32_t *__restrict__ ncount,
                                                   int32_t *__restrict__ wave_max, int32_t *__restrict__ flags,
                                                   const int32_t *__restrict__ orig, int32_t n_owned, int2 *__restrict__ deal,
-                                                  int32_t *__restrict__ plan_f) {
+                                                  int32_t *__restrict__ plan_f, int32_t *__restrict__ plan_h) {
     __shared__ double4 tile[T_NL];
     __shared__ int4 rowbuf[TB];                       // per lane: the row being filled, eight 16-bit entries (packing them in
     __shared__ int s_lo[4], s_hi[4];                  // registers cost the accept path 17 vector instructions instead of 6)
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
     uint16_t *myrow = reinterpret_cast<uint16_t *>(&rowbuf[threadIdx.x]);
     int cnt = 0;
     int plo[3], plen[3];
+    int hlo[2][3], hlen[2][3];                        // thread 0: the intervals of the two half groups (128 targets: waves 0-1, 2-3)
     int base = 0;                                     // tile slot of the current interval's first record
 
 #pragma unroll
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
         int lo, hi;
         block_interval(r, s_lo, s_hi, lo, hi);
         plo[o2 + 1] = lo; plen[o2 + 1] = hi > lo ? hi - lo : 0;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {              // (s_lo / s_hi: per-wave bounds, valid until the next block_interval)
+            const int l = min(s_lo[2 * hf], s_lo[2 * hf + 1]), h = max(s_hi[2 * hf], s_hi[2 * hf + 1]);
+            hlo[hf][o2 + 1] = l; hlen[hf][o2 + 1] = h > l ? h - l : 0;
+        }
         const int slot0 = base - lo;                  // entry of candidate j: its slot in this group's tile
         for (int cb = lo; cb < hi; cb += T_NL) {
             const int ce = min(cb + T_NL, hi);
@@ -146,6 +152,14 @@ __global__ __launch_bounds__(TB) void nlist_tiled(GridDesc g, const double4 *__r
         const int need = plen[0] + plen[1] + plen[2];
         p[0] = plo[0]; p[1] = plo[1]; p[2] = plo[2]; p[3] = plen[0]; p[4] = plen[1]; p[5] = plen[2]; p[6] = need;
         p[7] = max(max(s_lo[0], s_lo[1]), max(s_lo[2], s_lo[3]));
+        if (plan_h) {                                 // forces_q with eight lanes per target: groups of 128
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                int32_t *q = plan_h + 8 * (2 * (size_t)xcd_chunk(blockIdx.x, gridDim.x) + hf);
+                q[0] = hlo[hf][0]; q[1] = hlo[hf][1]; q[2] = hlo[hf][2]; q[3] = hlen[hf][0]; q[4] = hlen[hf][1]; q[5] = hlen[hf][2];
+                q[6] = hlen[hf][0] + hlen[hf][1] + hlen[hf][2]; q[7] = 0;
+            }
+        }
     }
     if (deal) {
         // forces_q deals the 256 targets of this workgroup (= one of its groups) to its lanes in order of list length,
@@ -347,15 +361,26 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                                                double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
                                                double *__restrict__ du, double *__restrict__ dalpha,
                                                const int32_t *__restrict__ orig, int32_t n_owned,
-                                               const int32_t *__restrict__ wave_class, int32_t want) {
-    static_assert(LPT == 4, "a list row holds four entries");
+                                               const int32_t *__restrict__ wave_class, int32_t want, const int32_t *__restrict__ plan256) {
+    // LPT = 4: groups of 256 targets, `plan` = plan_f (the groups the list entries are slots of), targets dealt by list length.
+    // LPT = 8: groups of 128 targets (half the tile need: neighbourhoods of ~200 that do not fit otherwise), `plan` = the
+    // half-group plans, plan256 = plan_f: an entry becomes a slot of the half group's tile with one constant per interval;
+    // a trip is a whole list row (eight entries, one per lane); targets in their natural order.
+    static_assert(LPT == 4 || LPT == 8, "a list row holds eight entries: two trips of four lanes or one of eight");
     constexpr int T = BS / LPT;
+    constexpr int TPR = 8 / LPT;                           // trips per list row
     extern __shared__ double lds_dyn[];
     double *lds_dw = lds_dyn;
     double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? ((pc.nq + 2) & ~1) : 0));      // !TAB: dW knots recomputed (density_wt)
     __shared__ int s_tgt[T];
-    const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x >> 2;
+    const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x / LPT;
     const double4 *fg = reinterpret_cast<const double4 *>(frec);
+    auto dealt = [&](int64_t g) -> int2 {                  // this thread's target in group g: {index within the group, list length or -1}
+        const int64_t t = g * T + tl;
+        if (t >= n) return make_int2(0, -1);
+        if (LPT == 4) return deal[t];
+        return make_int2(tl, orig[t] < n_owned ? min(ncount[t], cap) : -1);
+    };
     // the dw table once per workgroup: the kernel is persistent, one workgroup per CU walks over many groups of T targets
     if (TAB) {
         for (int t = threadIdx.x; t < ((pc.nq + 1) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     int2 deal_next = make_int2(0, -1);
     if (group < g_hi) {
         load_plan(plan, group, tm_next);
-        if (group * T + tl < n) deal_next = deal[group * T + tl];
+        deal_next = dealt(group);
     }
     for (; group < g_hi; group += per) {
         const int64_t base = group * T;
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const int2 dl = deal_next;
         if (group + per < g_hi) {
             load_plan(plan, group + per, tm_next);
-            deal_next = (group + per) * T + tl < n ? deal[(group + per) * T + tl] : make_int2(0, -1);
+            deal_next = dealt(group + per);
         }
         if (wave_class) {       // split evaluation (multi-GPU overlap): classes are per 64 targets
             bool any = false;
@@ -405,53 +430,64 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
         const int cnt = live ? dl.y : 0;
         __syncthreads();
-        // a trip = four consecutive entries of the target's list, one per lane: lane s reads word s of the list row (eight
-        // 16-bit entries), its low half in the even trip, its high half in the odd one (ent_pos, tile_common.hpp)
-        const int ntrip = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + 3) >> 2));
+        // a trip = LPT consecutive entries of the target's list, one per lane.  LPT = 4: lane s reads word s of the list row (eight
+        // 16-bit entries), its low half in the even trip, its high half in the odd one; LPT = 8: lane s reads word s & 3 and
+        // takes half s >> 2, a row per trip (ent_pos, tile_common.hpp)
+        const int ntrip = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + LPT - 1) / LPT));
         ForceSums f;
-        const uint32_t *lp = reinterpret_cast<const uint32_t *>(nlist) + (((size_t)(self >> 6) * (cap >> 3)) * 64 + (self & 63)) * 4 + sub;
+        const uint32_t *lp = reinterpret_cast<const uint32_t *>(nlist) + (((size_t)(self >> 6) * (cap >> 3)) * 64 + (self & 63)) * 4 + (sub & 3);
+        auto ent_of = [&](uint32_t wd, int hf) { return (int)((wd >> ((LPT == 4 ? hf : (sub >> 2)) << 4)) & 0xffffu); };
         if (ntrip > 0) {
-            const int nrow = (ntrip + 1) >> 1;
+            const int nrow = (ntrip + TPR - 1) / TPR;
             uint32_t wa = lp[0];
             uint32_t wb = lp[(size_t)min(1, nrow - 1) * 256];
+            // entries are slots of the 256-group's tile (LPT = 4: this tile) or, plus a constant per interval, of this half group's
+            // tile / the sorted order
             if (fits) {
-                // an entry IS the neighbour's slot in this group's tile
-                const double2 *rp = tile + q_unit(sub < cnt ? (int)(wa & 0xffffu) : 0);
+                EntryMap em{0, 0, 0, 0, 0};
+                if (LPT != 4) {
+                    em = entry_to_index(plan256, group >> 1);
+                    em.a0 = (int)((unsigned)em.a0 + (unsigned)tm.base[0] - (unsigned)tm.lo[0]);
+                    em.a1 = (int)((unsigned)em.a1 + (unsigned)tm.base[1] - (unsigned)tm.lo[1]);
+                    em.a2 = (int)((unsigned)em.a2 + (unsigned)tm.base[2] - (unsigned)tm.lo[2]);
+                }
+                auto slot_of = [&](int e) { return LPT == 4 ? e : em(e); };       // LPT = 4: an entry IS the slot
+                const double2 *rp = tile + q_unit(sub < cnt ? slot_of(ent_of(wa, 0)) : 0);
                 double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
                 for (int r = 0; r < nrow; r++) {
                     const uint32_t wc = lp[(size_t)min(r + 2, nrow - 1) * 256];
 #pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {
-                        if (hf == 1 && 2 * r + 1 >= ntrip) break;        // wave-uniform: the odd trip of the last row
+                    for (int hf = 0; hf < TPR; hf++) {
+                        if (TPR == 2 && hf == 1 && 2 * r + 1 >= ntrip) break;        // wave-uniform: the odd trip of the last row
                         const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
-                        const int k = 4 * (2 * r + hf) + sub;
-                        const int en = hf == 0 ? (int)(wa >> 16) : (int)(wb & 0xffffu);
-                        rp = tile + q_unit(k + 4 < cnt ? en : 0);
+                        const int k = LPT * (TPR * r + hf) + sub;
+                        const int en = (TPR == 2 && hf == 0) ? ent_of(wa, 1) : ent_of(wb, 0);
+                        rp = tile + q_unit(k + LPT < cnt ? slot_of(en) : 0);
                         r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
                         force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
                     }
                     wa = wb; wb = wc;
                 }
             } else {
-                const EntryMap em = entry_to_index(plan, group);
-                int j = sub < cnt ? em((int)(wa & 0xffffu)) : self;
+                const EntryMap em = entry_to_index(plan256, LPT == 4 ? group : (group >> 1));
+                int j = sub < cnt ? em(ent_of(wa, 0)) : self;
                 double4 A1 = fg[(size_t)j * 3], B1 = fg[(size_t)j * 3 + 1], C1 = fg[(size_t)j * 3 + 2];
                 for (int r = 0; r < nrow; r++) {
                     const uint32_t wc = lp[(size_t)min(r + 2, nrow - 1) * 256];
 #pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {
-                        if (hf == 1 && 2 * r + 1 >= ntrip) break;
+                    for (int hf = 0; hf < TPR; hf++) {
+                        if (TPR == 2 && hf == 1 && 2 * r + 1 >= ntrip) break;
                         const Nbr nb = nbr_of(A1, B1, C1);
-                        const int k = 4 * (2 * r + hf) + sub;
-                        const int en = hf == 0 ? (int)(wa >> 16) : (int)(wb & 0xffffu);
-                        if (k + 4 < cnt) { j = em(en); A1 = fg[(size_t)j * 3]; B1 = fg[(size_t)j * 3 + 1]; C1 = fg[(size_t)j * 3 + 2]; }
+                        const int k = LPT * (TPR * r + hf) + sub;
+                        const int en = (TPR == 2 && hf == 0) ? ent_of(wa, 1) : ent_of(wb, 0);
+                        if (k + LPT < cnt) { j = em(en); A1 = fg[(size_t)j * 3]; B1 = fg[(size_t)j * 3 + 1]; C1 = fg[(size_t)j * 3 + 2]; }
                         force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
                     }
                     wa = wb; wb = wc;
                 }
             }
         }
-        // the target's sums: (lane 0 + lane 1) + (lane 2 + lane 3), the same value in all four lanes
+        // the target's sums, added in a fixed tree over its LPT lanes: the same value in all of them
 #pragma unroll
         for (int o = 1; o < LPT; o <<= 1) {
             f.s0 += __shfl_xor(f.s0, o, 64); f.s1 += __shfl_xor(f.s1, o, 64); f.s2 += __shfl_xor(f.s2, o, 64);
@@ -488,11 +524,12 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
 // reductions and a barrier before the first byte could be staged: with one workgroup per CU nothing hides that.)
 __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, int64_t ngroups_f, const int32_t *__restrict__ plan_f, int32_t tcap_d,
                                                            int32_t tcap_f, int32_t tcap_d_big, int32_t tcap_f_big, int32_t *__restrict__ plan_d,
-                                                           int32_t *__restrict__ report) {
+                                                           const int32_t *__restrict__ plan_h, int32_t *__restrict__ report) {
     // ONE workgroup strides over the density groups (977 at 1e6 particles) and writes the four numbers straight into the host's
     // report slot (pinned memory mapped into the device's address space): no atomics, no device-to-host copy kernels
-    __shared__ int s_red[6][16];
+    __shared__ int s_red[8][16];
     int mx_list = 0, mx_need = 0, misfit_f = 0, misfit_d = 0, misfit_fb = 0, misfit_db = 0;      // ..b: against the table-free (bigger) tiles
+    int misfit_h = 0, misfit_hb = 0;                                                              // half groups (128 targets) of forces_q
     for (int64_t gd = threadIdx.x; gd < ngroups_d; gd += 1024) {
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
         for (int64_t gf = 4 * gd; gf < std::min<int64_t>(4 * gd + 4, ngroups_f); gf++) {
@@ -503,6 +540,12 @@ __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, in
             mx_need = max(mx_need, b.z); mx_list = max(mx_list, b.w);
             misfit_f += b.z > tcap_f ? 1 : 0;
             misfit_fb += b.z > tcap_f_big ? 1 : 0;
+            if (plan_h) {
+                for (int hf = 0; hf < 2; hf++) {
+                    const int nh = plan_h[8 * (2 * gf + hf) + 6];
+                    misfit_h += nh > tcap_f ? 1 : 0; misfit_hb += nh > tcap_f_big ? 1 : 0;
+                }
+            }
         }
         if (plan_d) {
             int need = 0;
@@ -521,17 +564,23 @@ __global__ __launch_bounds__(1024) void plan_reduce_kernel(int64_t ngroups_d, in
         mx_list = max(mx_list, __shfl_xor(mx_list, o, 64)); mx_need = max(mx_need, __shfl_xor(mx_need, o, 64));
         misfit_f += __shfl_xor(misfit_f, o, 64); misfit_d += __shfl_xor(misfit_d, o, 64);
         misfit_fb += __shfl_xor(misfit_fb, o, 64); misfit_db += __shfl_xor(misfit_db, o, 64);
+        misfit_h += __shfl_xor(misfit_h, o, 64); misfit_hb += __shfl_xor(misfit_hb, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         const int wv = threadIdx.x >> 6;
         s_red[0][wv] = mx_list; s_red[1][wv] = misfit_d; s_red[2][wv] = misfit_f; s_red[3][wv] = mx_need; s_red[4][wv] = misfit_db; s_red[5][wv] = misfit_fb;
+        s_red[6][wv] = misfit_h; s_red[7][wv] = misfit_hb;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
-        for (int k = 0; k < 16; k++) { r0 = max(r0, s_red[0][k]); r1 += s_red[1][k]; r2 += s_red[2][k]; r3 = max(r3, s_red[3][k]); r4 += s_red[4][k]; r5 += s_red[5][k]; }
-        // {longest list, misfits density, misfits forces, largest need, misfits density / forces with the table-free tiles}
-        report[0] = r0; report[1] = r1; report[2] = r2; report[3] = r3; report[4] = r4; report[5] = r5;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+        for (int k = 0; k < 16; k++) {
+            r0 = max(r0, s_red[0][k]); r1 += s_red[1][k]; r2 += s_red[2][k]; r3 = max(r3, s_red[3][k]); r4 += s_red[4][k]; r5 += s_red[5][k];
+            r6 += s_red[6][k]; r7 += s_red[7][k];
+        }
+        // {longest list, misfits density, misfits forces, largest need, misfits density / forces with the table-free tiles,
+        //  misfits of the half groups of forces_q with the table / table-free tile}
+        report[0] = r0; report[1] = r1; report[2] = r2; report[3] = r3; report[4] = r4; report[5] = r5; report[6] = r6; report[7] = r7;
     }
 }
 
@@ -598,12 +647,23 @@ int nlist_build_tiled(sph_ctx *c) {
             static const bool force_big = getenv("SPH_TILE_TABLE") && std::string(getenv("SPH_TILE_TABLE")) == "regs";
             const bool ok_d = (int64_t)rep[1] * 10 <= (int64_t)d_blocks, ok_db = (int64_t)rep[4] * 10 <= (int64_t)d_blocks;
             const bool ok_f = (int64_t)rep[2] * 10 <= (int64_t)f_blocks, ok_fb = (int64_t)rep[5] * 10 <= (int64_t)f_blocks;
+            // forces: groups of 256 with the table (1.0), table-free (x1.1 on the bench disc), groups of 128 -- eight lanes per
+            // target, every record staged more often -- with the table, table-free; the first whose tiles fit nine groups in ten
+            static const int force_half = getenv("SPH_FORCES_HALF_GROUPS") ? atoi(getenv("SPH_FORCES_HALF_GROUPS")) : 0;     // A/B switch
+            const bool ok_h = (int64_t)rep[6] * 10 <= 2 * (int64_t)f_blocks, ok_hb = (int64_t)rep[7] * 10 <= 2 * (int64_t)f_blocks;
             c->wt_big = force_big || (!ok_d && ok_db);
-            c->wt_big_f = force_big || (!ok_f && ok_fb);
             c->wt_ok = c->wt_big ? ok_db : ok_d;
-            c->wt_ok_f = c->wt_big_f ? ok_fb : ok_f;
             c->wt_fit_pct = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big ? 4 : 1]) / std::max<int64_t>(d_blocks, 1));
-            c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big_f ? 5 : 2]) / std::max<int64_t>(f_blocks, 1));
+            c->wt_half_f = force_half != 0 || (!ok_f && !ok_fb && (ok_h || ok_hb));
+            if (c->wt_half_f) {
+                c->wt_big_f = force_big || !ok_h;
+                c->wt_ok_f = c->wt_big_f ? ok_hb : ok_h;
+                c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big_f ? 7 : 6]) / std::max<int64_t>(2 * (int64_t)f_blocks, 1));
+            } else {
+                c->wt_big_f = force_big || (!ok_f && ok_fb);
+                c->wt_ok_f = c->wt_big_f ? ok_fb : ok_f;
+                c->wt_fit_pct_f = (int32_t)(100 - (100 * (int64_t)rep[c->wt_big_f ? 5 : 2]) / std::max<int64_t>(f_blocks, 1));
+            }
         }
     };
     // Steady state: the report of the PREVIOUS build (it arrived long ago) is read instead of waiting for this one's.  The
@@ -627,14 +687,14 @@ int nlist_build_tiled(sph_ctx *c) {
                                                                     n, pc.rcut2, c->nl_cap, reinterpret_cast<int4 *>(c->nlist),
                                                                     c->ncount, c->wave_max, c->d_flags, c->orig, (int32_t)c->n_owned,
                                                                     c->whole_tile ? reinterpret_cast<int2 *>(c->deal) : nullptr,
-                                                                    c->plan_f);
+                                                                    c->plan_f, c->whole_tile ? c->plan_h : nullptr);
         TL_CHECK(hipGetLastError());
         {
             const int64_t ngd = (n + WT_BS - 1) / WT_BS, ngf = (n + FQ_T - 1) / FQ_T;
             plan_reduce_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(
                 ngd, ngf, c->plan_f, c->whole_tile ? tile_cap(pc.nq, 4, true) : 0, c->whole_tile ? tile_cap_q(pc.nq) : LIST16_MAX_NEED,
                 c->whole_tile ? tile_cap(pc.nq, 4, false) : 0, c->whole_tile ? tile_cap_q(pc.nq, false) : LIST16_MAX_NEED,
-                c->whole_tile ? c->plan_d : nullptr, slot);
+                c->whole_tile ? c->plan_d : nullptr, c->whole_tile ? c->plan_h : nullptr, slot);
             TL_CHECK(hipGetLastError());
         }
         TL_CHECK(hipEventRecord(c->ev_nl[p], c->stream));
@@ -697,9 +757,9 @@ hipError_t launch_density_wt(sph_ctx *c, const PairConst &pc) {
     return c->wt_big ? density_wt_launch<false>(c, pc) : density_wt_launch<true>(c, pc);
 }
 
-template <bool TAB>
+template <int LPT, bool TAB>
 static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
-    constexpr int BS = 1024, LPT = 4;
+    constexpr int BS = 1024;
     const int32_t tcap = tile_cap_q(pc.nq, TAB);
     const size_t lds = (TAB ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -708,16 +768,18 @@ static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     const int64_t ngroups = (c->n + T - 1) / T;
     const unsigned grid = persistent_grid(c, ngroups);
     forces_q<BS, LPT, TAB><<<dim3(grid), dim3(BS), lds, c->stream>>>(
-        pc, tcap, (int32_t)ngroups, c->plan_f, reinterpret_cast<const int2 *>(c->deal), c->frec, c->nlist, c->nl_cap, c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
+        pc, tcap, (int32_t)ngroups, LPT == 4 ? c->plan_f : c->plan_h, LPT == 4 ? reinterpret_cast<const int2 *>(c->deal) : nullptr, c->frec, c->nlist, c->nl_cap,
+        c->ncount, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX],
         c->f[SPH_F_AY], c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned,
-        part ? c->wave_class : nullptr, part == 2 ? 1 : 0);
+        part ? c->wave_class : nullptr, part == 2 ? 1 : 0, c->plan_f);
     return hipGetLastError();
 }
 
 // part 0: every wave.  part 1 / 2: only the waves of class 0 (interior) / class 1, as launch_forces
 hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
-    return c->wt_big_f ? forces_q_launch<false>(c, pc, part) : forces_q_launch<true>(c, pc, part);
+    if (c->wt_half_f) return c->wt_big_f ? forces_q_launch<8, false>(c, pc, part) : forces_q_launch<8, true>(c, pc, part);
+    return c->wt_big_f ? forces_q_launch<4, false>(c, pc, part) : forces_q_launch<4, true>(c, pc, part);
 }
 
 }  // namespace sph

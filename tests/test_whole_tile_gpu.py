@@ -197,3 +197,39 @@ def test_dense_disc_runs_from_the_table_free_tiles(capi):
     assert sa.tile_fit_pct >= 90, (sa.tile_fit_pct, sa.tile_fit_pct_forces)      # the density geometry fits the table-free tile
     for f in FIELDS:
         assert same(a[f], b[f], f), f
+
+
+def test_half_group_forces_kernel_agrees(tmp_path):
+    """forces_q on groups of 128 targets (eight lanes per target, a list row per trip; what dense neighbourhoods get when
+    the tile of a group of 256 does not fit): forced with SPH_FORCES_HALF_GROUPS=1 on an ordinary stirred disc, it must give the
+    default kernel's forces up to the order in which a target's partial sums are added (<= 1e-14 of the field's scale),
+    with the table and table-free tiles alike, and the same 3-step trajectory to rounding"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from summersph_amd import capi, ic\n"
+        "gas, sinks = ic.split_rows(ic.keplerian_disc(90_001, seed=23, nngb=85.0))\n"
+        "rng = np.random.default_rng(4); gas['vx'] = gas['vx'] + rng.normal(0.0, 0.05, gas['x'].size); gas['alpha'] = np.full(gas['x'].size, 0.3)\n"
+        "ctx = capi.Context(device=0)\n"
+        "ctx.upload(gas); ctx.set_sinks(sinks)\n"
+        "ctx.density(); ctx.forces()\n"
+        "assert ctx.stats().tile_fit_pct_forces >= 90\n"
+        "ev = {f: ctx.field(f) for f in 'rho ax ay az du dalpha'.split()}\n"
+        "ctx.run(3, 1e-2, 0.0)\n"
+        "np.savez(sys.argv[1], **ev, **{'t_' + f: ctx.field(f) for f in 'x vx u alpha'.split()})\n"
+    )
+    out = {}
+    for tag, env in (("default", {}), ("half", {"SPH_FORCES_HALF_GROUPS": "1"}), ("half_regs", {"SPH_FORCES_HALF_GROUPS": "1", "SPH_TILE_TABLE": "regs"})):
+        path = tmp_path / f"{tag}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env={**os.environ, **env}, timeout=300)
+        out[tag] = dict(np.load(path))
+    for tag in ("half", "half_regs"):
+        assert np.array_equal(out[tag]["rho"], out["default"]["rho"])
+        for f in "ax ay az du dalpha".split():
+            assert same(out[tag][f], out["default"][f], f), (tag, f)
+        for f in "t_x t_vx t_u t_alpha".split():
+            assert float(np.max(np.abs(out[tag][f] - out["default"][f]))) <= 1e-12 * float(np.max(np.abs(out["default"][f]))), (tag, f)
