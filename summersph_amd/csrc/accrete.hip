@@ -49,6 +49,15 @@ __global__ __launch_bounds__(AB) void acc_keys(RootBox rb, const double4 *__rest
     vals[i] = (uint32_t)i;
 }
 
+// initiate_sink_accretion runs only if a sink has mass ([F]:919): decided on the device (the masses live there), so that the
+// pass needs no read-back for it.  Accretion only adds mass, so the answer is the same before and after the updates of a pass
+// in which it was false (nothing is marked then).
+__device__ __forceinline__ bool any_sink_mass(const double *__restrict__ sink, int ns) {
+    bool any = false;
+    for (int k = 0; k < ns; k++) any |= sink[6 * MAX_SINKS + k] > 0.0;
+    return any;
+}
+
 __device__ __forceinline__ int common_levels(uint64_t a, uint64_t b) {
     const uint64_t x = a ^ b;
     if (x == 0) return LEVELS;
@@ -59,10 +68,11 @@ __device__ __forceinline__ int common_levels(uint64_t a, uint64_t b) {
 __global__ __launch_bounds__(AB) void acc_mark(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                int64_t n, const double4 *__restrict__ drec, const int32_t *__restrict__ orig,
                                                const double *__restrict__ sink, const double *__restrict__ srad, int ns, int variant,
-                                               int do_accrete, double bound, int32_t *__restrict__ keep,
+                                               double bound, int32_t *__restrict__ keep,
                                                unsigned long long *__restrict__ accmask) {
     const int64_t s = (int64_t)blockIdx.x * AB + threadIdx.x;
     if (s >= n) return;
+    const bool do_accrete = any_sink_mass(sink, ns);
     const uint64_t key = keys[s];
     int cp = 0;
     if (s > 0) cp = max(cp, common_levels(key, keys[s - 1]));
@@ -106,10 +116,11 @@ __global__ __launch_bounds__(AB) void acc_mark(RootBox rb, const uint64_t *__res
 __global__ __launch_bounds__(AB) void acc_mark_ext(RootBox rb, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                    int64_t n_glob, int64_t src_off, int64_t n_owned, const double4 *__restrict__ drec,
                                                    const int32_t *__restrict__ inv, const double *__restrict__ sink,
-                                                   const double *__restrict__ srad, int ns, int variant, int do_accrete, double bound,
+                                                   const double *__restrict__ srad, int ns, int variant, double bound,
                                                    int32_t *__restrict__ keep, unsigned long long *__restrict__ accmask) {
     const int64_t s = (int64_t)blockIdx.x * AB + threadIdx.x;
     if (s >= n_glob) return;
+    const bool do_accrete = any_sink_mass(sink, ns);
     const int64_t id = (int64_t)vals[s] - src_off;
     if (id < 0 || id >= n_owned) return;
     const uint64_t key = keys[s];
@@ -150,8 +161,11 @@ __global__ __launch_bounds__(AB) void acc_mark_ext(RootBox rb, const uint64_t *_
 
 // sink k: sums over ranks (rank order) of the per-rank sums, then [F]:497-508
 __global__ void acc_sink_update_ranks(int ns, const double *__restrict__ all, int nranks, int stride, double *__restrict__ sink) {
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = any_sink_mass(sink, ns) ? 1 : 0;       // as of before any update of this pass
+    __syncthreads();
     const int k = threadIdx.x;
-    if (k >= ns) return;
+    if (k >= ns || !s_any) return;
     double v[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < nranks; r++)
         for (int q = 0; q < 7; q++) v[q] += all[(size_t)r * stride + (size_t)k * 7 + q];
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(AB) void acc_sums_partial(int64_t n, int k, const u
 }
 
 // [F]:497-508: new_mass, position and velocity become mass-weighted means, mass grows
-__global__ void acc_sink_update(int k, const double *__restrict__ part, int nb, double *__restrict__ sink) {
+__global__ void acc_sink_update(int k, int ns, const double *__restrict__ part, int nb, double *__restrict__ sink) {
     __shared__ double v[7];
     if (threadIdx.x < 7) {                       // one lane per sum, each over the blocks in the same fixed order as ever
         double r = 0.0;
@@ -212,7 +226,7 @@ __global__ void acc_sink_update(int k, const double *__restrict__ part, int nb, 
         v[threadIdx.x] = r;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || !any_sink_mass(sink, ns)) return;
     const double m0 = sink[6 * MAX_SINKS + k];
     const double nm = m0 + v[0];
     for (int a = 0; a < 3; a++) {
@@ -248,12 +262,15 @@ __global__ __launch_bounds__(AB) void acc_compact(CompactArgs a, const int32_t *
         }                                                                   \
     } while (0)
 
+__global__ void sink_cull(int ns, double bound, double *__restrict__ sink, double *__restrict__ srad, int32_t *__restrict__ ns_out);
+int sinks_cull(sph_ctx *c);
+
 // requires a valid grid (bbox, drec, orig/inv of the current positions).  On return the context holds only
 // the survivors, in the caller's order (like a fresh upload); *removed = how many particles left.
 int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     const int64_t n = c->n;
     *removed = 0;
-    if (n == 0) return SPH_OK;
+    if (n == 0) return sinks_cull(c);
     RootBox rb;
     double size = 0.0;
     for (int a = 0; a < 3; a++) {
@@ -263,12 +280,7 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     rb.size = size;
     const unsigned gb = (unsigned)((n + AB - 1) / AB);
     const double4 *drec = reinterpret_cast<const double4 *>(c->drec);
-    // sinks' masses decide whether accretion runs at all ([F]:919): read them (tiny)
-    std::vector<double> sm((size_t)MAX_SINKS);
-    AC_CHECK(hipMemcpyAsync(sm.data(), c->sink + (size_t)6 * MAX_SINKS, sizeof(double) * MAX_SINKS, hipMemcpyDeviceToHost, c->stream));
-    AC_CHECK(hipStreamSynchronize(c->stream));
-    bool any_mass = false;
-    for (int k = 0; k < c->ns; k++) any_mass |= sm[k] > 0.0;
+    // (whether accretion runs at all -- a sink with mass, [F]:919 -- is decided on the device: any_sink_mass)
 
     // the sorted path keys of the current grid build: left by the leaf-box build (variable h), copied from the self-gravity
     // tree of the last evaluation (same positions, same root box, same key), or computed and sorted here (0.2 ms at 1e6)
@@ -287,14 +299,14 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     int32_t *pos = reinterpret_cast<int32_t *>(c->keys_alt);
     unsigned long long *accmask = reinterpret_cast<unsigned long long *>(c->scratch);
     acc_mark<<<dim3(gb), dim3(AB), 0, c->stream>>>(rb, c->mkeys_alt, c->mvals_alt, n, drec, c->orig, c->sink, c->sink_radius, c->ns,
-                                                   c->variable ? 1 : 0, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
+                                                   c->variable ? 1 : 0, c->p.bounding_size, keep, accmask);
     AC_CHECK(hipGetLastError());
     if (d_keep_out) AC_CHECK(hipMemcpyAsync(d_keep_out, keep, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    if (any_mass) {
+    {
         const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
         for (int k = 0; k < c->ns; k++) {
             acc_sums_partial<<<dim3(nb), dim3(AB), 0, c->stream>>>(n, k, accmask, drec, c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->sink_part);
-            acc_sink_update<<<dim3(1), dim3(64), 0, c->stream>>>(k, c->sink_part, nb, c->sink);
+            acc_sink_update<<<dim3(1), dim3(64), 0, c->stream>>>(k, c->ns, c->sink_part, nb, c->sink);      // no-op without a massive sink
         }
         AC_CHECK(hipGetLastError());
     }
@@ -303,10 +315,19 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     AC_CHECK(rocprim::exclusive_scan(nullptr, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
     if (sb > c->sort_tmp_bytes) { c->err = "accrete: scan scratch too small"; return SPH_ERR_NOMEM; }
     AC_CHECK(rocprim::exclusive_scan(c->sort_tmp, sb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream));
-    int32_t last[2];
+    // ONE read-back per call: how many particles stay (and, variable h, how many sinks: [V]'s check_bounds culls sinks too)
+    if (c->variable && c->ns > 0) {
+        sink_cull<<<dim3(1), dim3(64), 0, c->stream>>>(c->ns, c->p.bounding_size, c->sink, c->sink_radius, c->d_flags + 2);
+        AC_CHECK(hipGetLastError());
+    }
+    int32_t *last = reinterpret_cast<int32_t *>(c->h_pinned + 300);
+    last[2] = c->ns;
     AC_CHECK(hipMemcpyAsync(&last[0], pos + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     AC_CHECK(hipMemcpyAsync(&last[1], keep + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->variable && c->ns > 0) AC_CHECK(hipMemcpyAsync(&last[2], c->d_flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     AC_CHECK(hipStreamSynchronize(c->stream));
+    c->host_syncs++;
+    if (last[2] != c->ns) { c->ns = last[2]; c->rates_valid = false; }
     const int64_t n_new = (int64_t)last[0] + last[1];
     if (n_new == n) return SPH_OK;                     // nobody left: sorted state stays as it is
     CompactArgs ca{};
@@ -335,7 +356,6 @@ int accrete_and_cull(sph_ctx *c, int64_t *removed, int32_t *d_keep_out) {
     c->n_owned = n_new;
     AC_CHECK(launch_iota(c, c->orig, n_new));
     AC_CHECK(launch_iota(c, c->inv, n_new));
-    AC_CHECK(hipStreamSynchronize(c->stream));
     c->grid_valid = c->rho_valid = c->eos_valid = c->rates_valid = c->tree_valid = c->order_valid = false;
     c->h_refresh_ok = false;
     c->path_keys_valid = false;
@@ -470,11 +490,6 @@ int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
         size = std::max(size, c->gx_box[3 + a] - c->gx_box[a]);
     }
     rb.size = size;
-    std::vector<double> sm((size_t)MAX_SINKS);
-    AC_CHECK(hipMemcpyAsync(sm.data(), c->sink + (size_t)6 * MAX_SINKS, sizeof(double) * MAX_SINKS, hipMemcpyDeviceToHost, c->stream));
-    AC_CHECK(hipStreamSynchronize(c->stream));
-    bool any_mass = false;
-    for (int k = 0; k < c->ns; k++) any_mass |= sm[k] > 0.0;
     int32_t *keep = reinterpret_cast<int32_t *>(c->keys);
     unsigned long long *accmask = reinterpret_cast<unsigned long long *>(c->scratch);
     AC_CHECK(hipMemsetAsync(keep, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1), c->stream));
@@ -483,9 +498,9 @@ int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
     if (no > 0 && ng > 0)
         acc_mark_ext<<<dim3((unsigned)((ng + AB - 1) / AB)), dim3(AB), 0, c->stream>>>(
             rb, c->g_keys_alt, c->g_vals_alt, ng, src_off, no, reinterpret_cast<const double4 *>(c->drec), c->inv, c->sink,
-            c->sink_radius, c->ns, c->variable ? 1 : 0, any_mass ? 1 : 0, c->p.bounding_size, keep, accmask);
+            c->sink_radius, c->ns, c->variable ? 1 : 0, c->p.bounding_size, keep, accmask);
     AC_CHECK(hipGetLastError());
-    if (any_mass && n > 0) {
+    if (n > 0) {             // (all zero without a massive sink: nothing is marked then)
         const int nb = (int)std::min<int64_t>((n + AB - 1) / AB, 256);
         for (int k = 0; k < c->ns; k++) {
             acc_sums_partial<<<dim3(nb), dim3(AB), 0, c->stream>>>(n, k, accmask, reinterpret_cast<const double4 *>(c->drec),
@@ -495,7 +510,6 @@ int accrete_mark_ext(sph_ctx *c, int64_t src_off, double *d_partials) {
         AC_CHECK(hipGetLastError());
     }
     c->acc_marked = true;
-    c->acc_any_mass = any_mass;
     return SPH_OK;
 }
 
@@ -504,7 +518,7 @@ int accrete_apply_ext(sph_ctx *c, const double *d_all, int nranks, int stride, i
     if (!c->acc_marked) { c->err = "sph_accrete_apply_dev: call sph_accrete_mark_dev first"; return SPH_ERR_STATE; }
     c->acc_marked = false;
     const int64_t n = c->n, no = c->n_owned;
-    if (c->acc_any_mass && c->ns > 0)
+    if (c->ns > 0)
         acc_sink_update_ranks<<<dim3(1), dim3(64), 0, c->stream>>>(c->ns, d_all, nranks, stride, c->sink);
     AC_CHECK(hipGetLastError());
     int32_t *keep = reinterpret_cast<int32_t *>(c->keys);

@@ -368,9 +368,9 @@ int do_accrete(sph_ctx *c, int64_t *removed, int32_t *d_keep = nullptr) {
         for (int a = 0; a < 6; a++) c->bbox[a] = bb[a];
         c->bbox_exact = true;
     }
-    API_TRY(accrete_and_cull(c, removed, d_keep));
+    API_TRY(accrete_and_cull(c, removed, d_keep));      // includes [V]'s cull of the sinks (Variable.f90:610-613)
     if (*removed > 0) c->numbers_set = false;           // the caller's numbering changed with the pack()
-    return sinks_cull(c);                               // Variable.f90:610-613 (after the accretion, like the gas cull)
+    return SPH_OK;
 }
 
 int one_step_device_dt(sph_ctx *c) {
