@@ -85,6 +85,9 @@ typedef struct sph_halo_stats {
     int64_t host_waits;    /* times the host waited for the device inside sph_halo_run                            */
     int64_t removed;       /* particles of this rank accreted or culled (since creation)                          */
     int64_t sinks_created; /* sinks created by check_sink_creation (the same on every rank)                       */
+    int64_t let_sent;      /* self-gravity, locally essential tree: particles + pseudo-particles this rank shipped  */
+    int64_t let_received;  /* ... and received (32 bytes each), summed over the source updates                      */
+    int64_t let_updates;   /* source updates (one per drift)                                                      */
 } sph_halo_stats;
 int sph_halo_get_stats(const sph_halo *h, sph_halo_stats *out);
 /* transport check: every rank sends `count` doubles to every rank (itself included) and verifies what arrives;

@@ -12,6 +12,9 @@
 // ("SUMMER_SPH - Variable.f90":1120-1158 for variable-h contexts).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -248,6 +251,92 @@ __global__ void pick_candidate(const double *__restrict__ all, int P, double *__
     for (int k = 0; k < 9; k++) out[k] = all[(size_t)best * 9 + k];
 }
 
+// ---- locally essential tree (self-gravity on several ranks) -----------------------------------------------------------------
+// The reference's octree over ALL particles ([F]:795-816: root = midpoint of the global bounding box, edge = its largest extent,
+// 8-way splits) fixes every cell; a particle's path down it is a 63-bit key (3 bits per level, as csrc/gravity.hip computes it).
+// A rank does not need the other ranks' particles one by one: a cell whose cube is so far from THIS rank's box that every
+// target in the box accepts it whatever its centre of mass inside the cube (edge^2 / theta^2 < dmin^2, dmin = distance box--cube;
+// [F]:278 tests edge / sqrt(|x - com|^2 + eps) < theta) is never opened here, so its sender ships it as ONE pseudo-particle
+// {centre of mass, mass} -- the coarsest such cell on the path of each of its particles -- and ships single particles only where
+// no cell on the path qualifies.  Acceptability is a property of (cell cube, receiver box): every sender cuts at the same cells,
+// a cell is either opened by all or shipped whole by all, and the receiver's tree over {own particles, received particles and
+// pseudo-particles} has, for every cell one of its targets opens, the same children occupancy, mass and centre of mass as the
+// global tree (sums in another order: rounding).
+struct LetRoot { double c[3]; double size; };
+struct LetBoxes { double b[MAXP][6]; int n; };
+
+__device__ __forceinline__ uint64_t let_key(const LetRoot &rb, double x, double y, double z) {
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    uint64_t key = 0;
+    for (int l = 0; l < 21; l++) {
+        const int bx = x > cx, by = y > cy, bz = z > cz;
+        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+        const double q = 0.25 * size;
+        cx = cx + (bx ? q : -q); cy = cy + (by ? q : -q); cz = cz + (bz ? q : -q);
+        size = size * 0.5;
+    }
+    return key;
+}
+
+// xyzm: [4][n] (rows x, y, z, m)
+__global__ void let_keys(LetRoot rb, const double *__restrict__ xyzm, int64_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = let_key(rb, xyzm[i], xyzm[n + i], xyzm[2 * n + i]);
+    vals[i] = (uint32_t)i;
+}
+
+// For receiver box b (blockIdx.y) and the particle at sorted position s: the level of the coarsest acceptable cell on its path
+// (22: none, the particle travels as itself); head[b n + s] = 1 where a new exported item starts; mom = {m x, m y, m z, m}.
+__global__ void let_cut(LetRoot rb, LetBoxes boxes, double inv_theta2, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                        const double *__restrict__ xyzm, int64_t n, int32_t *__restrict__ head, double4 *__restrict__ mom) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (s >= n) return;
+    const double *bx = boxes.b[b];
+    const uint64_t key = keys[s], prev = s > 0 ? keys[s - 1] : 0;
+    // levels this particle shares with its predecessor in key order (the predecessor's cut is the same on shared cells)
+    int lev = 22;
+    double cx = rb.c[0], cy = rb.c[1], cz = rb.c[2], size = rb.size;
+    for (int l = 0; l <= 21; l++) {
+        // cell at level l: cube (cx, cy, cz) +- size / 2
+        const double hx = 0.5 * size;
+        const double dx = fmax(fmax(bx[0] - (cx + hx), (cx - hx) - bx[3]), 0.0), dy = fmax(fmax(bx[1] - (cy + hx), (cy - hx) - bx[4]), 0.0),
+                     dz = fmax(fmax(bx[2] - (cz + hx), (cz - hx) - bx[5]), 0.0);
+        const double dmin2 = dx * dx + dy * dy + dz * dz;
+        if ((size * size) * inv_theta2 * (1.0 + 1e-9) < dmin2) { lev = l; break; }
+        if (l == 21) break;
+        const int ch = (int)((key >> (3 * (20 - l))) & 7);
+        const double q = 0.25 * size;
+        cx = cx + ((ch & 1) ? q : -q); cy = cy + ((ch & 2) ? q : -q); cz = cz + ((ch & 4) ? q : -q);
+        size = size * 0.5;
+    }
+    // same item as the predecessor iff both lie in the same acceptable cell: they share the first 3 lev bits of the key (then the
+    // predecessor's cut stops at the same cell)
+    bool first = s == 0 || lev == 22;
+    if (!first) first = lev == 0 ? false : ((key ^ prev) >> (3 * (21 - lev))) != 0;
+    head[(int64_t)b * n + s] = first ? 1 : 0;
+    const uint32_t i = vals[s];
+    const double m = xyzm[3 * n + i];
+    mom[(int64_t)b * n + s] = make_double4(m * xyzm[i], m * xyzm[n + i], m * xyzm[2 * n + i], m);
+}
+
+struct Add4 { __device__ double4 operator()(const double4 &a, const double4 &b) const { return make_double4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); } };
+
+// segment sums {m x, m y, m z, m} -> records {x, y, z, m} (a single particle comes out as itself up to one rounding of m x / m)
+__global__ void let_records(const double4 *__restrict__ sums, int64_t cnt, double4 *__restrict__ rec) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    const double4 v = sums[k];
+    rec[k] = v.w > 0.0 ? make_double4(v.x / v.w, v.y / v.w, v.z / v.w, v.w) : make_double4(0.0, 0.0, 0.0, 0.0);
+}
+
+// own particles as {x, y, z, m} records: rec[k] = {xyzm[k], xyzm[n + k], ...}
+__global__ void let_own_records(const double *__restrict__ xyzm, int64_t n, double4 *__restrict__ rec) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) rec[k] = make_double4(xyzm[k], xyzm[n + k], xyzm[2 * n + k], xyzm[3 * n + k]);
+}
+
 inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -273,6 +362,10 @@ struct sph_halo {
     bool pos_dirty = true, vel_dirty = false, dt_pending = false, pred_for_drift = false, pred_valid = false;
     DevBuf gid, gid_new, own, newbuf, part, allpart, row, box, boxes, cnt, cntall, ghosts, dest, flags, keep_ids, sel_tmp, sel_count;
     DevBuf src, srcmine, srcall, accp, accall, keep, cand, candall, gnum;
+    // locally essential tree: this rank's sorted path keys, the cut per receiver, the exported items
+    bool let = false;                    // self-gravity on several ranks through the LET exchange (fixed h) instead of the all-gather
+    double theta = 0.5;
+    DevBuf lkeys, lkeys2, lvals, lvals2, lsort, lhead, lseg, lmom, lsum, lukeys, lcount, lscan, lrec;
     DevBuf sendb[MAXP], recvb[MAXP], ids[MAXP];
     double *pin = nullptr;               // pinned host memory: the gathered partials, the boxes, the count matrix
     double *pin_part = nullptr, *pin_boxes = nullptr;
@@ -329,6 +422,10 @@ int common_init(sph_halo *h) {
     h->sink_creation = (p.flags & SPH_FLAG_SINK_CREATION) != 0 && h->variable;
     h->octree = h->gravity || h->variable;
     h->nf = h->variable ? 10 : 9;
+    h->theta = p.theta;
+    // fixed h: the gravity sources of the other ranks arrive as a locally essential tree (SPH_HALO_REPLICATED=1: every particle of
+    // every rank, as dist.py does; variable h keeps that -- the leaf boxes of the ghosts need their key neighbours one by one)
+    h->let = h->gravity && !h->variable && h->P > 1 && getenv("SPH_HALO_REPLICATED") == nullptr;
     if (h->accrete && h->P > 1 && !h->octree) {
         // the accretion test walks the octree of ALL particles: it needs the all-gathered sources of the self-gravity path
         h->err = "sph_halo: accretion on several ranks needs SPH_FLAG_SELF_GRAVITY or SPH_FLAG_VARIABLE_H (the shared octree)";
@@ -801,6 +898,101 @@ int reduce_finish(sph_halo *h, bool before_drift) {
     return SPH_OK;
 }
 
+// self-gravity sources as a locally essential tree: own particles + what every other rank cut for this rank's box
+int gravity_sources_let(sph_halo *h) {
+    static const int32_t XYZM[4] = {SPH_F_X, SPH_F_Y, SPH_F_Z, SPH_F_M};
+    const int P = h->P;
+    const int64_t n = h->n_owned;
+    // the global root box: every rank's exact box of this exchange
+    auto finite6 = [&](int q) { for (int a = 0; a < 6; a++) if (!std::isfinite(h->last_boxes[(size_t)q * 6 + a])) return false; return true; };
+    double lo_hi[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    LetBoxes lb{};
+    int peer_of[MAXP];
+    lb.n = 0;
+    for (int q = 0; q < P; q++) {
+        if (!finite6(q)) continue;
+        for (int a = 0; a < 3; a++) {
+            lo_hi[a] = std::min(lo_hi[a], h->last_boxes[(size_t)q * 6 + a]);
+            lo_hi[3 + a] = std::max(lo_hi[3 + a], h->last_boxes[(size_t)q * 6 + 3 + a]);
+        }
+        if (q == h->rank) continue;
+        for (int a = 0; a < 6; a++) lb.b[lb.n][a] = h->last_boxes[(size_t)q * 6 + a];
+        peer_of[lb.n++] = q;
+    }
+    LetRoot rb;
+    rb.size = 0.0;
+    for (int a = 0; a < 3; a++) { rb.c[a] = (lo_hi[3 + a] + lo_hi[a]) / 2.0; rb.size = std::max(rb.size, lo_hi[3 + a] - lo_hi[a]); }
+    const int nb = lb.n;
+    int64_t sendc[MAXP];
+    for (int q = 0; q < P; q++) sendc[q] = 0;
+    H_HIP(h->srcmine.need((size_t)std::max<int64_t>(n, 1) * 4 * 8));
+    if (n > 0) H_TRY(sph_gather_fields_dev(h->c, 4, XYZM, n, nullptr, h->srcmine.as<double>()));       // [4][n]
+    if (n > 0 && nb > 0) {
+        if ((int64_t)nb * n >= 2147483647LL) { h->err = "sph_halo: LET cut larger than 2^31 items"; return SPH_ERR_ARG; }
+        const size_t items = (size_t)nb * (size_t)n;
+        H_HIP(h->lkeys.need((size_t)n * 8)); H_HIP(h->lkeys2.need((size_t)n * 8));
+        H_HIP(h->lvals.need((size_t)n * 4)); H_HIP(h->lvals2.need((size_t)n * 4));
+        H_HIP(h->lhead.need(items * 4)); H_HIP(h->lseg.need(items * 4));
+        H_HIP(h->lmom.need(items * 32)); H_HIP(h->lsum.need(items * 32)); H_HIP(h->lukeys.need(items * 4));
+        H_HIP(h->lcount.need(64));
+        let_keys<<<blocks_for(n), 256, 0, h->s0>>>(rb, h->srcmine.as<double>(), n, h->lkeys.as<uint64_t>(), h->lvals.as<uint32_t>());
+        H_HIP(hipGetLastError());
+        size_t t1 = 0, t2 = 0, t3 = 0;
+        H_HIP(rocprim::radix_sort_pairs(nullptr, t1, h->lkeys.as<uint64_t>(), h->lkeys2.as<uint64_t>(), h->lvals.as<uint32_t>(), h->lvals2.as<uint32_t>(),
+                                        (size_t)n, 0u, 63u, h->s0));
+        H_HIP(rocprim::inclusive_scan(nullptr, t2, h->lhead.as<int32_t>(), h->lseg.as<int32_t>(), items, rocprim::plus<int32_t>(), h->s0));
+        H_HIP(rocprim::reduce_by_key(nullptr, t3, h->lseg.as<int32_t>(), h->lmom.as<double4>(), items, h->lukeys.as<int32_t>(), h->lsum.as<double4>(),
+                                     h->lcount.as<unsigned int>(), Add4(), rocprim::equal_to<int32_t>(), h->s0));
+        H_HIP(h->lsort.need(std::max(t1, std::max(t2, t3))));
+        H_HIP(rocprim::radix_sort_pairs(h->lsort.p, t1, h->lkeys.as<uint64_t>(), h->lkeys2.as<uint64_t>(), h->lvals.as<uint32_t>(), h->lvals2.as<uint32_t>(),
+                                        (size_t)n, 0u, 63u, h->s0));
+        let_cut<<<dim3(blocks_for(n).x, (unsigned)nb), 256, 0, h->s0>>>(rb, lb, 1.0 / (h->theta * h->theta), h->lkeys2.as<uint64_t>(), h->lvals2.as<uint32_t>(),
+                                                                         h->srcmine.as<double>(), n, h->lhead.as<int32_t>(), h->lmom.as<double4>());
+        H_HIP(hipGetLastError());
+        H_HIP(rocprim::inclusive_scan(h->lsort.p, t2, h->lhead.as<int32_t>(), h->lseg.as<int32_t>(), items, rocprim::plus<int32_t>(), h->s0));
+        H_HIP(rocprim::reduce_by_key(h->lsort.p, t3, h->lseg.as<int32_t>(), h->lmom.as<double4>(), items, h->lukeys.as<int32_t>(), h->lsum.as<double4>(),
+                                     h->lcount.as<unsigned int>(), Add4(), rocprim::equal_to<int32_t>(), h->s0));
+        // items per receiver: the running item number at the end of each receiver's block (one read-back)
+        for (int b = 0; b < nb; b++)
+            H_HIP(hipMemcpyAsync(h->pin_row + b, h->lseg.as<int32_t>() + ((size_t)(b + 1) * n - 1), 4, hipMemcpyDeviceToHost, h->s0));
+        if (int st = host_wait(h, h->s0)) return st;
+        int64_t before = 0;
+        H_HIP(h->lrec.need((size_t)std::max<int64_t>((int64_t)reinterpret_cast<int32_t *>(h->pin_row + nb - 1)[0], 1) * 32));
+        const int64_t total = reinterpret_cast<int32_t *>(h->pin_row + nb - 1)[0];
+        let_records<<<blocks_for(total), 256, 0, h->s0>>>(h->lsum.as<double4>(), total, h->lrec.as<double4>());
+        H_HIP(hipGetLastError());
+        for (int b = 0; b < nb; b++) {
+            const int64_t upto = reinterpret_cast<int32_t *>(h->pin_row + b)[0];
+            sendc[peer_of[b]] = upto - before;
+            before = upto;
+        }
+    }
+    // counts: who sends how much to whom (P x P on the host), then one grouped round of {x, y, z, m} records
+    std::vector<int64_t> cm((size_t)P * P);
+    if (int st = gather_counts(h, sendc, cm.data())) return st;
+    const void *sp[MAXP];
+    void *rp[MAXP];
+    size_t sb[MAXP], rbytes[MAXP];
+    int64_t recv_total = 0, off_send = 0;
+    for (int q = 0; q < P; q++) { sp[q] = nullptr; rp[q] = nullptr; sb[q] = 0; rbytes[q] = 0; }
+    for (int q = 0; q < P; q++) if (q != h->rank) recv_total += cm[(size_t)q * P + h->rank];
+    H_HIP(h->src.need((size_t)std::max<int64_t>(n + recv_total, 1) * 32));
+    if (n > 0) { let_own_records<<<blocks_for(n), 256, 0, h->s0>>>(h->srcmine.as<double>(), n, h->src.as<double4>()); H_HIP(hipGetLastError()); }
+    int64_t off_recv = n;
+    for (int q = 0; q < P; q++) {
+        if (q == h->rank) continue;
+        if (sendc[q] > 0) { sp[q] = h->lrec.as<double4>() + off_send; sb[q] = (size_t)sendc[q] * 32; off_send += sendc[q]; }
+        const int64_t rq = cm[(size_t)q * P + h->rank];
+        if (rq > 0) { rp[q] = h->src.as<double4>() + off_recv; rbytes[q] = (size_t)rq * 32; off_recv += rq; }
+    }
+    if (int st = s0_then_s1(h)) return st;
+    if (int st = p2p_raw(h, sp, sb, rp, rbytes)) return st;
+    if (int st = s1_then_s0(h)) return st;
+    h->st.let_sent += off_send; h->st.let_received += recv_total; h->st.let_updates++;
+    H_TRY(sph_set_gravity_sources_dev(h->c, n + recv_total, h->src.as<double>(), lo_hi));
+    return SPH_OK;
+}
+
 // one force evaluation: create_tree .. find_forces of the reference, [F]:894-898 (dist.py evaluate)
 int evaluate(sph_halo *h, bool before_drift) {
     static const int32_t RHO[2] = {SPH_F_RHO, SPH_F_OMEGA};
@@ -814,7 +1006,7 @@ int evaluate(sph_halo *h, bool before_drift) {
         }
         if (multi) if (int st = exchange_ghosts(h)) return st;
         if (multi && h->octree && !h->sources_valid) {
-            if (int st = gravity_sources(h)) return st;
+            if (int st = h->let ? gravity_sources_let(h) : gravity_sources(h)) return st;
             h->sources_valid = true;
         }
         if (!multi && h->variable && h->n_owned > 0) H_TRY(sph_set_numbers_dev(h->c, 0, h->n_owned, h->gid.as<int64_t>()));
@@ -870,8 +1062,8 @@ int accrete_and_cull(sph_halo *h) {
         H_TRY(sph_accrete_and_cull_keep(h->c, h->keep.as<int32_t>(), &removed));
         if (removed > 0) h->pos_dirty = true;          // variable h: the survivors' numbers are set again before the next pass
     } else {
-        int64_t off = 0;
-        for (int q = 0; q < h->rank; q++) off += h->counts_all[q];
+        int64_t off = 0;                            // where this rank's particles sit in the source set (LET: they lead it)
+        if (!h->let) for (int q = 0; q < h->rank; q++) off += h->counts_all[q];
         H_HIP(h->accp.need(ACC_PARTIALS * 8));
         H_HIP(h->accall.need((size_t)P * ACC_PARTIALS * 8));
         H_TRY(sph_accrete_mark_dev(h->c, off, h->accp.as<double>()));
@@ -973,7 +1165,8 @@ void destroy_impl(sph_halo *h) {
     delete h->tr;
     for (DevBuf *b : {&h->gid, &h->gid_new, &h->own, &h->newbuf, &h->part, &h->allpart, &h->row, &h->box, &h->boxes, &h->cnt, &h->cntall,
                       &h->ghosts, &h->dest, &h->flags, &h->keep_ids, &h->sel_tmp, &h->sel_count, &h->src, &h->srcmine, &h->srcall, &h->accp,
-                      &h->accall, &h->keep, &h->cand, &h->candall, &h->gnum}) b->release();
+                      &h->accall, &h->keep, &h->cand, &h->candall, &h->gnum, &h->lkeys, &h->lkeys2, &h->lvals, &h->lvals2, &h->lsort, &h->lhead,
+                      &h->lseg, &h->lmom, &h->lsum, &h->lukeys, &h->lcount, &h->lscan, &h->lrec}) b->release();
     for (int q = 0; q < MAXP; q++) { h->sendb[q].release(); h->recvb[q].release(); h->ids[q].release(); }
     if (h->pin) (void)hipHostFree(h->pin);
     for (hipEvent_t e : {h->e01, h->e10, h->e_pred}) if (e) (void)hipEventDestroy(e);

@@ -29,7 +29,7 @@ _lib = None
 
 
 class HaloStats(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in "ghosts migrated exchanges collectives migrations host_waits removed sinks_created".split()]
+    _fields_ = [(k, C.c_int64) for k in "ghosts migrated exchanges collectives migrations host_waits removed sinks_created let_sent let_received let_updates".split()]
 
 
 def load():

@@ -14,6 +14,7 @@ module sph_hip_halo_binding
 
   type, bind(C) :: sph_halo_stats
     integer(c_int64_t) :: ghosts, migrated, exchanges, collectives, migrations, host_waits, removed, sinks_created
+    integer(c_int64_t) :: let_sent, let_received, let_updates
   end type sph_halo_stats
 
   interface

@@ -538,3 +538,28 @@ def test_native_loop_one_rank_is_sph_run_on_the_octree_paths(flavour):
     # the survivors kept their global numbers: exactly the particles the reference kept
     assert np.all(np.diff(one["state"]["gid"]) > 0)
     ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_locally_essential_tree_matches_the_replicated_tree(world, monkeypatch):
+    """self-gravity on several ranks: by default every rank ships, per receiver box, the coarsest octree cells that box accepts
+    whatever their centre of mass (as {com, mass} pseudo-particles) and single particles elsewhere; SPH_HALO_REPLICATED=1 ships
+    every particle to everybody (what dist.py does).  Same accepted sets for every target, sums in another order: identical dt
+    decisions, states equal to <= 1e-12 -- and far fewer bytes"""
+    rows = ic.keplerian_disc(40_000, seed=47, nngb=85.0)
+    gas, sinks = ic.split_rows(rows)
+    kw = dict(flags=capi.FLAG_SELF_GRAVITY | capi.FLAG_ACCRETE_CULL)
+    let = _run_ranks_ex(world, gas, sinks, 4, kw)
+    monkeypatch.setenv("SPH_HALO_REPLICATED", "1")
+    rep = _run_ranks_ex(world, gas, sinks, 4, kw)
+    n_total = gas["x"].size
+    for a, b in zip(let, rep):
+        assert a["dts"] == b["dts"] and list(a["ns"]) == list(b["ns"])
+        assert a["stats"].let_updates > 0 and b["stats"].let_updates == 0
+        # per source update a rank receives far fewer records than the other ranks hold
+        others = n_total - a["state"]["x"].size
+        assert a["stats"].let_received / a["stats"].let_updates < 0.5 * others
+    for f in FIELDS:
+        assert rel_err(_merged(let, f), _merged(rep, f)) <= 1e-12, f
+    for k in ("x", "vx", "m"):
+        assert np.max(np.abs(let[0]["sinks"][k] - rep[0]["sinks"][k])) <= 1e-13
