@@ -110,8 +110,8 @@ int ensure_capacity(sph_ctx *c, int64_t n) {
 #pragma clang fp contract(off)
 void host_tables(int nq, std::vector<double> &w, std::vector<double> &dw) {
     // SUMMER_SPH.f90:55-79 (cubic spline M4 sampled on q in [0,2]); dq = 2.0_dp/nq
-    w.assign((size_t)nq + 1, 0.0);
-    dw.assign((size_t)nq + 1, 0.0);
+    w.assign((size_t)TAB_LEN(nq), 0.0);        // knots 0..nq + one zero of padding (table_lerp)
+    dw.assign((size_t)TAB_LEN(nq), 0.0);
     const double dq = 2.0 / nq;
     for (int i = 0; i <= nq; i++) {
         const double q = i * dq;
@@ -538,7 +538,7 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     c->tiled = !c->variable && (p->flags & SPH_FLAG_NO_LDS_TILES) == 0;
     // whole-tile kernels: 116 KB tile + the kernel table must fit the 160 KB of LDS (nq <= ~5500)
     c->whole_tile = c->tiled && (p->flags & SPH_FLAG_NO_WHOLE_TILE) == 0 &&
-                    (size_t)((p->nq + 2) & ~1) * sizeof(double) + (size_t)WT_TILE_RECORDS * 32 + 1024 <= (size_t)160 * 1024;
+                    (size_t)TAB_LDS(p->nq) * sizeof(double) + (size_t)WT_TILE_RECORDS * 32 + 1024 <= (size_t)160 * 1024;
     c->packed_list = c->tiled;
     c->device = device;
     DeviceGuard g(device);
@@ -555,8 +555,8 @@ int sph_ctx_create(const sph_params *p, int device, sph_ctx **out) {
     if ((st = ctx_alloc(c, &c->bbox_part, (size_t)1024 * 8 + 64, "bbox")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->d_flags, 8, "flags")) != SPH_OK) return fail(st);
     if (hipMemset(c->d_flags, 0, 8 * sizeof(int32_t)) != hipSuccess) return fail(SPH_ERR_HIP);
-    if ((st = ctx_alloc(c, &c->w_tab, (size_t)p->nq + 1, "W table")) != SPH_OK) return fail(st);
-    if ((st = ctx_alloc(c, &c->dw_tab, (size_t)p->nq + 1, "dW table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->w_tab, (size_t)TAB_LEN(p->nq), "W table")) != SPH_OK) return fail(st);
+    if ((st = ctx_alloc(c, &c->dw_tab, (size_t)TAB_LEN(p->nq), "dW table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->grav_tab, (size_t)p->nq + 1, "softening table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->w_pair, (size_t)2 * p->nq, "W pair table")) != SPH_OK) return fail(st);
     if ((st = ctx_alloc(c, &c->dw_pair, (size_t)2 * p->nq, "dW pair table")) != SPH_OK) return fail(st);

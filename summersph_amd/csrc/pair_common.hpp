@@ -48,13 +48,13 @@ __device__ __forceinline__ int comp4(const int4 &v, int u) { return u == 0 ? v.x
 // nine of them.  The kernels use the hardware seed (v_rcp_f64 / v_rsq_f64) plus Newton / Goldschmidt
 // steps instead: results are within ~1 ulp of the correctly rounded quotient, i.e. the same size as
 // the summation-order noise that is there anyway (parity tolerance 1e-13, tests/test_parity_gpu.py).
+// (Seeds measured on gfx950, tests/tools/seed: v_rcp_f64 and v_rsq_f64 are good to 2^-24.  ONE third-order step therefore
+// reaches 2^-70 -- e = 1 - x r, r (1 + e + e^2) -- in three instructions where two Newton steps take four; likewise
+// y (1 + e/2 + 3 e^2/8) with e = 1 - x y^2 for the reciprocal square root, five instructions instead of eight.)
 __device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(e, r, r);
-    e = fma(-x, r, 1.0);
-    r = fma(e, r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 
 // s = sqrt(x), rs = 1/sqrt(x) for x > 0 (x == 0 gives s = 0 and a finite rs the caller masks)
@@ -72,29 +72,59 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &s, double &rs)
     rs = h + h;
 }
 
-// rs = 1/sqrt(x) alone, x > 0 (two Newton steps on the hardware seed: ~1 ulp); the gravity walk needs the distance
+// s = sqrt(x) and rs = 1/sqrt(x) from ONE reciprocal square root refined by one third-order step, s = x rs (x == 0: s = 0 up to
+// 1e-150, rs finite; the caller masks it).  ~1.5 ulp in s against the ~0.5 of fast_sqrt_rsqrt, three vector instructions fewer
+// per pair visit -- used by the fixed-h pair terms since round 3 (the pair sums' parity margin is 1e-13 against ~1e-15).
+__device__ __forceinline__ void rsqrt_sqrt(double x, double &s, double &rs) {
+    const double xs = fmax(x, 1e-300);
+    const double y0 = __builtin_amdgcn_rsq(xs);
+    const double e = fma(-(xs * y0), y0, 1.0);
+    const double y = fma(y0, fma(0.375, e, 0.5) * e, y0);
+    rs = y;
+    s = x * y;
+}
+
+// 1/a and 1/b from ONE reciprocal: r = 1/(a b) (fast_rcp), 1/a = b r, 1/b = a r.  a, b > 0 and their
+// product far from over- / underflow (squared distances and densities here).
+__device__ __forceinline__ void rcp_pair(double a, double b, double &ra, double &rb) {
+    const double r = fast_rcp(a * b);
+    ra = b * r;
+    rb = a * r;
+}
+
+// rs = 1/sqrt(x) alone, x > 0 (one third-order step on the hardware seed: ~1 ulp); the gravity walk needs the distance
 // itself only inside the softening support
 __device__ __forceinline__ double fast_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-(x * y), y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-(x * y), y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y, fma(0.375, e, 0.5) * e, y);
 }
 
 // lookup_kernel's interpolation (SUMMER_SPH.f90:114-118), table in LDS or global; returns the
 // un-normalised value.  k = min(int(q/dq), nq-1), a = (q - k dq)/dq are evaluated as q*(1/dq):
 // identical except within an ulp of a table knot, where the (continuous) interpolant changes by O(1e-16).
+// The W / dW tables carry ONE ENTRY OF PADDING (TAB_LEN(nq) = nq + 2 values, the last one 0 like the knot at q = 2): the
+// reference's clamp k <= nq-1 only matters at q = 2 exactly, where it yields t[nq] = 0; with the padding k = nq, a = 0 gives
+// the same 0 without the clamp, and a = fract(t) replaces the int -> double conversion and a subtraction (callers pass
+// q <= 2, so k <= nq up to the rounding of 2/dq, which lands on the two zero entries).
 // (The pair terms are written with explicit fma() under contract(off): which products the compiler fuses would otherwise
 // depend on the kernel a term is inlined into, and the kernel sets -- pairs.hip, the tile variants of tiled.hip -- could
 // not be compared bitwise.)
-__device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double inv_dq, int nq) {
-#pragma clang fp contract(off)
+// The lookup in two halves, so that a kernel can put work between the request of the two knots and their use: the knots of
+// a table in LDS come back behind whatever the wave asked of the LDS before them.
+struct Knots { double t0, t1, a; };
+__device__ __forceinline__ Knots table_knots(const double *__restrict__ tab, double qi, double inv_dq) {
     const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k;
-    return fma(a, tab[k + 1], (1.0 - a) * tab[k]);
+    const int k = (int)t;
+    return Knots{tab[k], tab[k + 1], __builtin_amdgcn_fract(t)};
+}
+__device__ __forceinline__ double knots_value(const Knots &kn) {
+#pragma clang fp contract(off)
+    return fma(kn.a, kn.t1, (1.0 - kn.a) * kn.t0);
+}
+__device__ __forceinline__ double table_lerp(const double *__restrict__ tab, double qi, double inv_dq, int nq) {
+    (void)nq;
+    return knots_value(table_knots(tab, qi, inv_dq));
 }
 
 // The table values themselves, recomputed: knot k of the W / dW table exactly as host_tables (api.hip, [F]:55-79) fills it --
@@ -119,20 +149,23 @@ __device__ __forceinline__ double dw_knot(int k, double dq) {
 }
 // lookup_kernel's interpolation with a knot function instead of a table in memory
 template <class KnotFn>
-__device__ __forceinline__ double knot_lerp(KnotFn knot, double qi, double inv_dq, int nq) {
-#pragma clang fp contract(off)
+__device__ __forceinline__ Knots knot_knots(KnotFn knot, double qi, double inv_dq) {
     const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k;
-    return fma(a, knot(k + 1), (1.0 - a) * knot(k));
+    const int k = (int)t;
+    return Knots{knot(k), knot(k + 1), __builtin_amdgcn_fract(t)};
+}
+template <class KnotFn>
+__device__ __forceinline__ double knot_lerp(KnotFn knot, double qi, double inv_dq, int nq) {
+    (void)nq;
+    return knots_value(knot_knots(knot, qi, inv_dq));
 }
 
 // both tables at once (same knot, same weight)
 __device__ __forceinline__ void table_lerp2(const double *__restrict__ tw, const double *__restrict__ tdw, double qi,
                                             double inv_dq, int nq, double &w, double &dw) {
     const double t = qi * inv_dq;
-    const int k = min((int)t, nq - 1);
-    const double a = t - (double)k, b = 1.0 - a;
+    const int k = (int)t;
+    const double a = __builtin_amdgcn_fract(t), b = 1.0 - a;
     w = b * tw[k] + a * tw[k + 1];
     dw = b * tdw[k] + a * tdw[k + 1];
 }
@@ -151,22 +184,30 @@ __device__ __forceinline__ void write_frec(double *__restrict__ frec, int64_t i,
 }
 
 // one visit of the density sum, [F]:443-455: acc += m_j w(q_ij) (un-normalised, [F]:125 is applied once at the end)
-// w_of(q): the interpolated, un-normalised W table value (table_lerp on a table in LDS, or knot_lerp)
-template <class WFn>
-__device__ __forceinline__ void density_visit_fn(const double4 &pi, const double4 &pj, bool act, WFn w_of, double inv_h, double &acc) {
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// w_of(q): the two knots of the un-normalised W table around q (table_knots on a table in LDS, or knot_knots); next(): what the
+// caller wants issued right behind that request -- the tile kernels read the NEXT neighbour's record there, so that the knots
+// are at the head of the wave's LDS queue and not behind six record reads
+template <class WFn, class Next = NoPrefetch>
+__device__ __forceinline__ void density_visit_fn(const double4 &pi, const double4 &pj, bool act, WFn w_of, double inv_h, double &acc,
+                                                 Next next = Next()) {
 #pragma clang fp contract(off)
     const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;     // [F]:445
     double dr, rs;
-    fast_sqrt_rsqrt(fma(n2, n2, fma(n1, n1, n0 * n0)), dr, rs);             // [F]:446
+    rsqrt_sqrt(fma(n2, n2, fma(n1, n1, n0 * n0)), dr, rs);                  // [F]:446
     const double qi = dr * inv_h;                                          // [F]:111
     // no control flow: a lane that does not count ([F]:113: q > 2; idle lanes) adds an exact zero, and consecutive visits
     // can overlap
+    const Knots kn = w_of(fmin(qi, 2.0));
+    next();
     const double mj = (act && qi <= 2.0) ? pj.w : 0.0;
-    acc = fma(mj, w_of(fmin(qi, 2.0)), acc);                               // [F]:114-118,454
+    acc = fma(mj, knots_value(kn), acc);                                   // [F]:114-118,454
 }
 __device__ __forceinline__ void density_visit(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lds_w,
                                               double inv_h, double inv_dq, int nq, double &acc) {
-    density_visit_fn(pi, pj, act, [&](double q) { return table_lerp(lds_w, q, inv_dq, nq); }, inv_h, acc);
+    (void)nq;
+    density_visit_fn(pi, pj, act, [&](double q) { return table_knots(lds_w, q, inv_dq); }, inv_h, acc);
 }
 
 // self term, normalisation, EOS and the force record of particle i ([F]:443-455 visits the particle's own leaf: r = 0;
@@ -194,35 +235,38 @@ __device__ __forceinline__ Nbr nbr_of(const double4 &A, const double4 &B, const 
     return Nbr{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z};
 }
 
-// one visit of the fixed-h force sums, gather form of [F]:356-391.  A, B, C: the target's record; dw_of(q): the
-// interpolated, un-normalised dw table value.  Beyond 2h every term is exactly 0; r == 0 (coincident points): DESIGN.md.
-// one visit of the fixed-h force sums, gather form of [F]:356-391.  A, B, C: the target's record; dw_of(q): the interpolated,
-// un-normalised dw table value.  Written without control flow: a lane that does not count (beyond 2h every term is exactly
-// 0; r == 0: coincident points; idle lanes) adds exact zeros -- every intermediate is finite (r2 + eps > 0,
-// rho > 0, the table index is clamped) -- and with no branch between them the dependent chains of consecutive visits
-// overlap (forces_q 0.63 -> 0.59 ms per step).
-template <class DwFn>
+// one visit of the fixed-h force sums, gather form of [F]:356-391.  A, B, C: the target's record; dw_of(q): the two knots of the
+// un-normalised dw table around q; next(): issued right behind that request (density_visit_fn).  Written without control flow:
+// a lane that does not count (beyond 2h every term is exactly 0; r == 0: coincident points; idle lanes) adds exact
+// zeros -- every intermediate is finite (r2 + eps > 0, rho > 0, the table is padded) -- and with no branch between them the
+// dependent chains of consecutive visits overlap.  The viscosity chain, which does not need the table, is written between the
+// request of the knots and their use.
+template <class DwFn, class Next = NoPrefetch>
 __device__ __forceinline__ void force_visit(const PairConst &pc, double inv_h, const double4 &A, const double4 &B, const double4 &C,
-                                            const Nbr &j, bool act, DwFn dw_of, ForceSums &f) {
+                                            const Nbr &j, bool act, DwFn dw_of, ForceSums &f, Next next = Next()) {
 #pragma clang fp contract(off)
     const double n0 = A.x - j.x, n1 = A.y - j.y, n2 = A.z - j.z;                  // [F]:356
     const double r2 = fma(n2, n2, fma(n1, n1, n0 * n0));
     double dr, rs;
-    fast_sqrt_rsqrt(r2, dr, rs);                                                  // [F]:357
+    rsqrt_sqrt(r2, dr, rs);                                                       // [F]:357
     const double qi = dr * inv_h;
+    const Knots kn = dw_of(fmin(qi, 2.0));
+    next();
     const bool on = act && qi <= 2.0 && r2 > 0.0;
     const double v0 = B.x - j.vx, v1 = B.y - j.vy, v2 = B.z - j.vz;               // [F]:358
     const double vdotr = fmin(fma(v2, n2, fma(v1, n1, v0 * n0)), 0.0);            // [F]:359-361
-    const double dWm = dw_of(fmin(qi, 2.0)) * rs;                                 // [F]:366; rs: the 1/dr of [F]:363
-    const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                     // [F]:363,368
-    const double vdotgradW = fma(g2, v2, fma(g1, v1, g0 * v0));                   // [F]:370
-    const double vis_nu = (pc.h * vdotr) * fast_rcp(r2 + pc.visc_eps_h2);         // [F]:373
+    double inv_r2e, inv_rho;                                                      // 1 / (r^2 + 0.01 h^2), 1 / rho_bar: one reciprocal
+    rcp_pair(r2 + pc.visc_eps_h2, B.w + j.rho_h, inv_r2e, inv_rho);
+    const double vis_nu = (pc.h * vdotr) * inv_r2e;                               // [F]:373
     const double cbar = C.x + j.c_h;                                              // [F]:374 (halves stored)
     const double abar = C.y + j.al_h;                                             // [F]:376
-    const double visc = ((abar * vis_nu) * fma(2.0, vis_nu, -cbar)) * fast_rcp(B.w + j.rho_h);   // [F]:378
+    const double visc = ((abar * vis_nu) * fma(2.0, vis_nu, -cbar)) * inv_rho;    // [F]:378
     const double Cf = (C.z + j.P_r2) + visc;                                      // [F]:381-382
     const double mj = on ? j.m : 0.0;
     const double mC = mj * Cf;
+    const double dWm = knots_value(kn) * rs;                                      // [F]:366; rs: the 1/dr of [F]:363
+    const double g0 = n0 * dWm, g1 = n1 * dWm, g2 = n2 * dWm;                     // [F]:363,368
+    const double vdotgradW = fma(g2, v2, fma(g1, v1, g0 * v0));                   // [F]:370
     f.s0 = fma(mC, g0, f.s0); f.s1 = fma(mC, g1, f.s1); f.s2 = fma(mC, g2, f.s2); // [F]:383
     const double mv = mj * vdotgradW;
     f.sdu = fma(mv, fma(0.5, visc, C.z), f.sdu);                                  // [F]:387

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
                                                         double *__restrict__ frec, const int32_t *__restrict__ orig,
                                                         int32_t n_owned, const int32_t *__restrict__ plan_f) {
     extern __shared__ double lds_w[];
-    for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_w[k] = w_tab[k];
+    for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += BLOCK) lds_w[k] = w_tab[k];
     __syncthreads();
 
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
             any |= ((w0 + k) << 6) < n && wave_class[w0 + k] == want;
         if (!any) return;
     }
-    for (int k = threadIdx.x; k <= pc.nq; k += BLOCK) lds_dw[k] = dw_tab[k];
+    for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += BLOCK) lds_dw[k] = dw_tab[k];
     __syncthreads();
 
     if ((i & ~(int64_t)63) >= n) return;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
 
     ForceSums f;
-    auto dw_of = [&](double q) { return table_lerp(lds_dw, q, inv_dq, pc.nq); };
+    auto dw_of = [&](double q) { return table_knots(lds_dw, q, inv_dq); };
     int j1 = 0 < cnt ? mine(0) : self;
     int j2 = 1 < cnt ? mine(1) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);
@@ -396,7 +396,7 @@ static int gather_block(const sph_ctx *) {
 
 hipError_t launch_density(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    const size_t lds = (size_t)TAB_LEN(pc.nq) * sizeof(double);
     if (gather_block(c) == 64) {
         auto k64 = c->packed_list ? density_kernel<64, true> : density_kernel<64, false>;
         k64<<<dim3((unsigned)((c->n + 63) / 64)), dim3(64), lds, c->stream>>>(
@@ -425,7 +425,7 @@ hipError_t launch_eos_only(sph_ctx *c, const PairConst &pc, bool ghosts_only) {
 // part 0: every wave.  part 1 / 2: only the waves of class 0 (interior: no lane within 2h of a ghost box) / class 1
 hipError_t launch_forces(sph_ctx *c, const PairConst &pc, int part) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    const size_t lds = (size_t)TAB_LEN(pc.nq) * sizeof(double);
     if (gather_block(c) == 64) {
         auto k64 = c->packed_list ? forces_kernel<64, true> : forces_kernel<64, false>;
         k64<<<dim3((unsigned)((c->n + 63) / 64)), dim3(64), lds, c->stream>>>(

@@ -12,6 +12,10 @@
 
 namespace sph {
 
+// W / dW table length in doubles (one entry of zero padding behind the knot at q = 2, see table_lerp in pair_common.hpp) and its LDS footprint
+constexpr int TAB_LEN(int nq) { return nq + 2; }
+constexpr int TAB_LDS(int nq) { return (nq + 3) & ~1; }
+
 constexpr int WAVE = 64;           // CDNA wavefront
 constexpr int FREC = 12;           // doubles per force gather record
 constexpr int MAX_SINKS = 64;      // sinks handled by the in-kernel loops

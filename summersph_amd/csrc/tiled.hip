@@ -252,17 +252,17 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                                                  double *__restrict__ rho, double *__restrict__ P, double *__restrict__ cs,
                                                  double *__restrict__ frec, const int32_t *__restrict__ orig, int32_t n_owned) {
     extern __shared__ double lds_dyn[];
-    double *lds_w = lds_dyn;                                               // nq+1 doubles (padded to even)
-    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TAB ? ((pc.nq + 2) & ~1) : 0));
+    double *lds_w = lds_dyn;                                               // TAB_LEN(nq) doubles (padded to even)
+    double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TAB ? (TAB_LDS(pc.nq)) : 0));
     // persistent, as forces_q: one workgroup per CU walks over groups of BS targets; the table once, the plan one group ahead;
     // XCD x works on one contiguous eighth of the groups (its L2 then holds what neighbouring groups stage twice)
-    if (TAB) for (int k = threadIdx.x; k <= pc.nq; k += BS) lds_w[k] = w_tab[k];
+    if (TAB) for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += BS) lds_w[k] = w_tab[k];
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const int lane = threadIdx.x & 63;
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
     auto w_of = [&](double q) {
-        return TAB ? table_lerp(lds_w, q, inv_dq, pc.nq) : knot_lerp([&](int k) { return w_knot(k, pc.dq); }, q, inv_dq, pc.nq);
+        return TAB ? table_knots(lds_w, q, inv_dq) : knot_knots([&](int k) { return w_knot(k, pc.dq); }, q, inv_dq);
     };
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                     for (int v = 0; v < 4; v++) {             // whole halves, no trip-count test: the trips past the wave's
                         const int k = 8 * r + 4 * hh + v;     // longest list are masked like any idle lane
                         const double4 pj = p1;
-                        p1 = tile[k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : 0];
-                        density_visit_fn(pi, pj, k < cnt, w_of, inv_h, acc);
+                        const int s1 = k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : 0;
+                        density_visit_fn(pi, pj, k < cnt, w_of, inv_h, acc, [&]() { p1 = tile[s1]; });     // the next record: behind the knots
                     }
                 }
                 qa = qb; qb = qc;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     constexpr int TPR = 8 / LPT;                           // trips per list row
     extern __shared__ double lds_dyn[];
     double *lds_dw = lds_dyn;
-    double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? ((pc.nq + 2) & ~1) : 0));      // !TAB: dW knots recomputed (density_wt)
+    double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? (TAB_LDS(pc.nq)) : 0));      // !TAB: dW knots recomputed (density_wt)
     __shared__ int s_tgt[T];
     const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x / LPT;
     const double4 *fg = reinterpret_cast<const double4 *>(frec);
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     };
     // the dw table once per workgroup: the kernel is persistent, one workgroup per CU walks over many groups of T targets
     if (TAB) {
-        for (int t = threadIdx.x; t < ((pc.nq + 1) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
-        if (threadIdx.x == 0 && ((pc.nq + 1) & 1)) lds_dw[pc.nq] = dw_tab[pc.nq];
+        for (int t = threadIdx.x; t < (TAB_LEN(pc.nq) >> 1); t += BS) reinterpret_cast<double2 *>(lds_dw)[t] = reinterpret_cast<const double2 *>(dw_tab)[t];
+        if (threadIdx.x == 0 && (TAB_LEN(pc.nq) & 1)) lds_dw[TAB_LEN(pc.nq) - 1] = dw_tab[TAB_LEN(pc.nq) - 1];
     }
     // workgroups b, b + 8, .. share an XCD (round-robin dispatch, speed only): XCD x works on one contiguous eighth of the
     // groups, so that the up to nine workgroups that stage a record find it in that XCD's L2; its workgroups take the
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
     auto dw_of = [&](double q) {
-        return TAB ? table_lerp(lds_dw, q, inv_dq, pc.nq) : knot_lerp([&](int k) { return dw_knot(k, pc.dq); }, q, inv_dq, pc.nq);
+        return TAB ? table_knots(lds_dw, q, inv_dq) : knot_knots([&](int k) { return dw_knot(k, pc.dq); }, q, inv_dq);
     };
     // what does not need the tile is fetched one group ahead: the plan and the dealt target of this thread
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
@@ -463,8 +463,10 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                         const int k = LPT * (TPR * r + hf) + sub;
                         const int en = (TPR == 2 && hf == 0) ? ent_of(wa, 1) : ent_of(wb, 0);
                         rp = tile + q_unit(k + LPT < cnt ? slot_of(en) : 0);
-                        r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5];
-                        force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f);
+                        // the next record is read behind this visit's two table knots: the LDS answers a wave in order, and the
+                        // knots are what the visit waits for
+                        force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f,
+                                    [&]() { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5]; });
                     }
                     wa = wb; wb = wc;
                 }
@@ -589,14 +591,14 @@ inline unsigned tb_blocks(int64_t n) { return (unsigned)((n + TB - 1) / TB); }
 constexpr int FQ_T = 256;            // forces_q: targets per group
 
 int32_t tile_cap(int nq, int rec, bool tablds) {
-    const size_t tab = tablds ? (size_t)((nq + 2) & ~1) * sizeof(double) : 0;
+    const size_t tab = tablds ? (size_t)(TAB_LDS(nq)) * sizeof(double) : 0;
     if (tab + LDS_RESERVE >= (size_t)LDS_BYTES) return 0;
     return (int32_t)(((size_t)LDS_BYTES - LDS_RESERVE - tab) / ((size_t)rec * sizeof(double)));
 }
 
 // forces_q: 6 units of 16 bytes per record + 1 per eight records
 int32_t tile_cap_q(int nq, bool tablds = true) {
-    const size_t tab = tablds ? (size_t)((nq + 2) & ~1) * sizeof(double) : 0;
+    const size_t tab = tablds ? (size_t)(TAB_LDS(nq)) * sizeof(double) : 0;
     constexpr size_t reserve = 4096;            // static LDS of forces_q
     if (tab + reserve + 64 >= (size_t)LDS_BYTES) return 0;
     const size_t units = ((size_t)LDS_BYTES - reserve - tab) / 16 - 2;
@@ -740,7 +742,7 @@ static unsigned persistent_grid(const sph_ctx *c, int64_t ngroups) {
 template <bool TAB>
 static hipError_t density_wt_launch(sph_ctx *c, const PairConst &pc) {
     const int32_t tcap = tile_cap(pc.nq, 4, TAB);
-    const size_t lds = (TAB ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + (size_t)tcap * sizeof(double4);
+    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + (size_t)tcap * sizeof(double4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
@@ -761,7 +763,7 @@ template <int LPT, bool TAB>
 static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     constexpr int BS = 1024;
     const int32_t tcap = tile_cap_q(pc.nq, TAB);
-    const size_t lds = (TAB ? (size_t)((pc.nq + 2) & ~1) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
+    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     constexpr int T = BS / LPT;

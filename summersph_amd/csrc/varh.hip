@@ -641,8 +641,8 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
                                                            double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec,
                                                            const int32_t *__restrict__ orig, int32_t n_owned) {
     extern __shared__ double lds[];
-    double *lw = lds, *ldw = lds + (pc.nq + 1);
-    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
+    double *lw = lds, *ldw = lds + TAB_LEN(pc.nq);
+    for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
     __syncthreads();
 
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
@@ -714,8 +714,8 @@ __global__ __launch_bounds__(VBLOCK) void reflag_density_kernel(PairConst pc, co
                                                                 double *__restrict__ rho, double *__restrict__ omega,
                                                                 double *__restrict__ P, double *__restrict__ cs, double *__restrict__ frec) {
     extern __shared__ double lds[];
-    double *lw = lds, *ldw = lds + (pc.nq + 1);
-    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
+    double *lw = lds, *ldw = lds + TAB_LEN(pc.nq);
+    for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += VBLOCK) { lw[k] = w_tab[k]; ldw[k] = dw_tab[k]; }
     __syncthreads();
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
     if ((i & ~(int64_t)63) >= n) return;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
                                                           double *__restrict__ du, double *__restrict__ dalpha,
                                                           const int32_t *__restrict__ orig, int32_t n_owned) {
     extern __shared__ double lds_dw[];
-    for (int k = threadIdx.x; k <= pc.nq; k += VBLOCK) lds_dw[k] = dw_tab[k];
+    for (int k = threadIdx.x; k < TAB_LEN(pc.nq); k += VBLOCK) lds_dw[k] = dw_tab[k];
     __syncthreads();
 
     const int64_t i = (int64_t)xcd_chunk(blockIdx.x, gridDim.x) * VBLOCK + threadIdx.x;
@@ -1219,7 +1219,7 @@ int varh_nlist_reflag(sph_ctx *c) {
 int varh_reflag_density(sph_ctx *c, const PairConst &pc) {
     const int64_t n = c->n;
     if (n == 0) return SPH_OK;
-    const size_t lds = (size_t)(pc.nq + 1) * 2 * sizeof(double);
+    const size_t lds = (size_t)TAB_LEN(pc.nq) * 2 * sizeof(double);
     reflag_density_kernel<<<dim3((unsigned)((n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->prec), reinterpret_cast<const double4 *>(c->lrec), reinterpret_cast<const double4 *>(c->drec),
         c->f[SPH_F_M], c->orig, n, (int32_t)c->n_owned, c->nl_cap, c->nlist, c->ncount, c->ntail, c->wave_max,
@@ -1233,7 +1233,7 @@ int varh_reflag_density(sph_ctx *c, const PairConst &pc) {
 
 hipError_t launch_density_v(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)(pc.nq + 1) * 2 * sizeof(double);
+    const size_t lds = (size_t)TAB_LEN(pc.nq) * 2 * sizeof(double);
     density_v_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
         pc, reinterpret_cast<const double4 *>(c->drec), c->nlist, c->nl_cap, c->ncount, c->wave_max, c->w_tab, c->dw_tab, c->n,
         c->f[SPH_F_H], c->f[SPH_F_U], c->f[SPH_F_ALPHA], c->f[SPH_F_VX], c->f[SPH_F_VY], c->f[SPH_F_VZ], c->f[SPH_F_RHO],
@@ -1251,7 +1251,7 @@ hipError_t launch_eos_only_v(sph_ctx *c, const PairConst &pc) {
 
 hipError_t launch_forces_v(sph_ctx *c, const PairConst &pc) {
     if (c->n == 0) return hipSuccess;
-    const size_t lds = (size_t)(pc.nq + 1) * sizeof(double);
+    const size_t lds = (size_t)TAB_LEN(pc.nq) * sizeof(double);
     forces_v_kernel<<<dim3((unsigned)((c->n + VBLOCK - 1) / VBLOCK)), dim3(VBLOCK), lds, c->stream>>>(
         pc, c->frec, c->nlist, c->nl_cap, c->ncount, c->wave_max, c->dw_tab, c->sink, c->n, c->f[SPH_F_AX], c->f[SPH_F_AY],
         c->f[SPH_F_AZ], c->f[SPH_F_DU], c->f[SPH_F_DALPHA], c->orig, (int32_t)c->n_owned);
