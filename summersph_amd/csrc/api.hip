@@ -113,7 +113,7 @@ void host_tables(int nq, std::vector<double> &w, std::vector<double> &dw) {
     w.assign((size_t)TAB_LEN(nq), 0.0);        // knots 0..nq + one zero of padding (table_lerp)
     dw.assign((size_t)TAB_LEN(nq), 0.0);
     const double dq = 2.0 / nq;
-    for (int i = 0; i <= nq; i++) {
+    for (int i = 0; i < nq; i++) {         // knot nq (q = 2, where W = dW = 0) stays an exact zero whatever nq * dq rounds to
         const double q = i * dq;
         if (q >= 0.0 && q <= 1.0) {
             w[i] = 1.0 - 1.5 * (q * q) + 0.75 * (q * q * q);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include "sph_internal.hpp"
 
 namespace sph {
@@ -113,11 +114,17 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // The lookup in two halves, so that a kernel can put work between the request of the two knots and their use: the knots of
 // a table in LDS come back behind whatever the wave asked of the LDS before them.
 struct Knots { double t0, t1, a; };
-__device__ __forceinline__ Knots table_knots(const double *__restrict__ tab, double qi, double inv_dq) {
-    const double t = qi * inv_dq;
+__device__ __forceinline__ Knots table_knots_at(const double *__restrict__ tab, double t) {      // t = q / dq, 0 <= t <= nq (+ an ulp)
     const int k = (int)t;
     return Knots{tab[k], tab[k + 1], __builtin_amdgcn_fract(t)};
 }
+__device__ __forceinline__ Knots table_knots(const double *__restrict__ tab, double qi, double inv_dq) {
+    return table_knots_at(tab, qi * inv_dq);
+}
+// t for ANY q >= 0, with 1/dq = nq/2 EXACTLY (the kernels pass 0.5 * nq: dq = 2/nq, [F]:58): beyond the support t is nq exactly,
+// where both knots are the zeros at the table's end -- a pair beyond 2h (and the far-away sentinel record the tile kernels give
+// their idle lanes) then adds an exact zero with no test of q at all
+__device__ __forceinline__ double knot_coord(double qi, double inv_dq) { return fmin(qi, 2.0) * inv_dq; }
 __device__ __forceinline__ double knots_value(const Knots &kn) {
 #pragma clang fp contract(off)
     return fma(kn.a, kn.t1, (1.0 - kn.a) * kn.t0);
@@ -131,29 +138,30 @@ __device__ __forceinline__ double table_lerp(const double *__restrict__ tab, dou
 // q = k dq, the same expressions under contract(off), so bitwise the table's values.  The whole-tile kernels use this when
 // the 40-KB table would not leave the tile enough LDS (dense neighbourhoods): ~12 vector instructions per knot instead of an
 // LDS read, which is still far cheaper than falling back to the direct gathers.
-__device__ __forceinline__ double w_knot(int k, double dq) {
+__device__ __forceinline__ double w_knot(int k, double dq, int nq) {
 #pragma clang fp contract(off)
     const double q = k * dq;
     const double t = 2.0 - q;
     const double a = 1.0 - 1.5 * (q * q) + 0.75 * (q * q * q);
     const double b = 0.25 * (t * t * t);
-    return (q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0);
+    return k >= nq ? 0.0 : ((q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0));       // knot nq (q = 2) and the padding: 0
 }
-__device__ __forceinline__ double dw_knot(int k, double dq) {
+__device__ __forceinline__ double dw_knot(int k, double dq, int nq) {
 #pragma clang fp contract(off)
     const double q = k * dq;
     const double t = 2.0 - q;
     const double a = -3.0 * q + 2.25 * (q * q);
     const double b = -0.75 * (t * t);
-    return (q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0);
+    return k >= nq ? 0.0 : ((q >= 0.0 && q <= 1.0) ? a : ((q > 1.0 && q <= 2.0) ? b : 0.0));
 }
 // lookup_kernel's interpolation with a knot function instead of a table in memory
 template <class KnotFn>
-__device__ __forceinline__ Knots knot_knots(KnotFn knot, double qi, double inv_dq) {
-    const double t = qi * inv_dq;
+__device__ __forceinline__ Knots knot_knots_at(KnotFn knot, double t) {
     const int k = (int)t;
     return Knots{knot(k), knot(k + 1), __builtin_amdgcn_fract(t)};
 }
+template <class KnotFn>
+__device__ __forceinline__ Knots knot_knots(KnotFn knot, double qi, double inv_dq) { return knot_knots_at(knot, qi * inv_dq); }
 template <class KnotFn>
 __device__ __forceinline__ double knot_lerp(KnotFn knot, double qi, double inv_dq, int nq) {
     (void)nq;
@@ -189,7 +197,9 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // w_of(q): the two knots of the un-normalised W table around q (table_knots on a table in LDS, or knot_knots); next(): what the
 // caller wants issued right behind that request -- the tile kernels read the NEXT neighbour's record there, so that the knots
 // are at the head of the wave's LDS queue and not behind six record reads
-template <class WFn, class Next = NoPrefetch>
+// MASK: the caller's idle lanes carry an arbitrary record and act = false (their mass counts as 0); !MASK: they carry the far-away,
+// massless sentinel record, and the visit has no predicate at all (act is ignored) -- the same sums bitwise, both add exact zeros
+template <bool MASK = true, class WFn, class Next = NoPrefetch>
 __device__ __forceinline__ void density_visit_fn(const double4 &pi, const double4 &pj, bool act, WFn w_of, double inv_h, double &acc,
                                                  Next next = Next()) {
 #pragma clang fp contract(off)
@@ -199,15 +209,15 @@ __device__ __forceinline__ void density_visit_fn(const double4 &pi, const double
     const double qi = dr * inv_h;                                          // [F]:111
     // no control flow: a lane that does not count ([F]:113: q > 2; idle lanes) adds an exact zero, and consecutive visits
     // can overlap
-    const Knots kn = w_of(fmin(qi, 2.0));
+    const Knots kn = w_of(qi);                                             // [F]:113: beyond 2h the knots are the table's final zeros
     next();
-    const double mj = (act && qi <= 2.0) ? pj.w : 0.0;
+    const double mj = (!MASK || act) ? pj.w : 0.0;
     acc = fma(mj, knots_value(kn), acc);                                   // [F]:114-118,454
 }
 __device__ __forceinline__ void density_visit(const double4 &pi, const double4 &pj, bool act, const double *__restrict__ lds_w,
                                               double inv_h, double inv_dq, int nq, double &acc) {
     (void)nq;
-    density_visit_fn(pi, pj, act, [&](double q) { return table_knots(lds_w, q, inv_dq); }, inv_h, acc);
+    density_visit_fn(pi, pj, act, [&](double q) { return table_knots_at(lds_w, knot_coord(q, inv_dq)); }, inv_h, acc);
 }
 
 // self term, normalisation, EOS and the force record of particle i ([F]:443-455 visits the particle's own leaf: r = 0;
@@ -241,7 +251,7 @@ __device__ __forceinline__ Nbr nbr_of(const double4 &A, const double4 &B, const 
 // zeros -- every intermediate is finite (r2 + eps > 0, rho > 0, the table is padded) -- and with no branch between them the
 // dependent chains of consecutive visits overlap.  The viscosity chain, which does not need the table, is written between the
 // request of the knots and their use.
-template <class DwFn, class Next = NoPrefetch>
+template <bool MASK = true, class DwFn, class Next = NoPrefetch>
 __device__ __forceinline__ void force_visit(const PairConst &pc, double inv_h, const double4 &A, const double4 &B, const double4 &C,
                                             const Nbr &j, bool act, DwFn dw_of, ForceSums &f, Next next = Next()) {
 #pragma clang fp contract(off)
@@ -250,9 +260,10 @@ __device__ __forceinline__ void force_visit(const PairConst &pc, double inv_h, c
     double dr, rs;
     rsqrt_sqrt(r2, dr, rs);                                                       // [F]:357
     const double qi = dr * inv_h;
-    const Knots kn = dw_of(fmin(qi, 2.0));
+    const Knots kn = dw_of(qi);               // beyond 2h: the table's final zeros; r == 0: dw(0) = 0 -- g, and with it every term, is 0
     next();
-    const bool on = act && qi <= 2.0 && r2 > 0.0;
+    if constexpr (!std::is_same<Next, NoPrefetch>::value) __builtin_amdgcn_sched_barrier(0);     // both requests leave before the rest
+    const bool on = !MASK || act;
     const double v0 = B.x - j.vx, v1 = B.y - j.vy, v2 = B.z - j.vz;               // [F]:358
     const double vdotr = fmin(fma(v2, n2, fma(v1, n1, v0 * n0)), 0.0);            // [F]:359-361
     double inv_r2e, inv_rho;                                                      // 1 / (r^2 + 0.01 h^2), 1 / rho_bar: one reciprocal

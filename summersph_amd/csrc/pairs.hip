@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
 
     // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
     // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
 
     ForceSums f;
-    auto dw_of = [&](double q) { return table_knots(lds_dw, q, inv_dq); };
+    auto dw_of = [&](double q) { return table_knots_at(lds_dw, knot_coord(q, inv_dq)); };
     int j1 = 0 < cnt ? mine(0) : self;
     int j2 = 1 < cnt ? mine(1) : self;
     const double4 *fj = reinterpret_cast<const double4 *>(frec + (size_t)j1 * FREC);

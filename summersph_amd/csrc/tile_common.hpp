@@ -17,6 +17,7 @@ namespace sph {
 // The three intervals of a group must stay below 65536 records together (LIST16_MAX_NEED); a context whose groups outgrow
 // that (a very dense thick domain) falls back to the untiled 32-bit list of pairs.hip for good (nlist_build_tiled).
 constexpr int LIST16_MAX_NEED = 65536;
+constexpr double SENTINEL_POS = 1.0e30;       // coordinates of the sentinel record of the whole-tile kernels (tiled.hip): q is astronomically > 2
 __device__ __host__ __forceinline__ int ent_pos(int k) { return ((k & 3) << 1) | ((k >> 2) & 1); }
 // halfword p (compile-time in the unrolled loops) of a row
 __device__ __forceinline__ int row_entry(const int4 &q, int p) {
@@ -79,6 +80,26 @@ __device__ __forceinline__ void load_plan(const int32_t *__restrict__ plan, int6
 // of 16 bytes; unit t of the tile goes to dst[SWZ ? q_unit(s) + part : t].  U loads in flight per thread: staging is
 // latency-bound (one workgroup per CU, nothing else to run), so what counts is the number of round trips.
 __device__ __forceinline__ int q_unit(int s) { return 6 * s + (s >> 3); }
+// the same as a byte offset, for a slot below 2^16: 16 (6 s + s/8) = 16 floor(49 s / 8) = (98 s) & ~15 -- a 24-bit multiply and a mask
+__device__ __forceinline__ const double2 *q_record(const double2 *tile, int s) {
+    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tile) + (__umul24((unsigned)s, 98u) & ~15u));
+}
+// The U loaded values, pinned between the loads and the stores.  Without it the compiler sinks each clamped load into the
+// conditional block of its store and the tile arrives in U consecutive round trips per trip of the loop (seen in the ISA of
+// round 3: global_load, s_waitcnt vmcnt(0), ds_write, U times); with it the U loads are issued back to back and waited for once.
+template <int U>
+__device__ __forceinline__ void pin_loaded(double2 (&v)[U]) {
+    static_assert(U == 4 || U == 6 || U == 8, "stage_tile: 4, 6 or 8 loads in flight");
+    if constexpr (U == 4)
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y));
+    else if constexpr (U == 6)
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+                          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y));
+    else
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+                          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+}
+
 template <int BS, int U, int UPR, bool SWZ>
 __device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
     const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
@@ -90,6 +111,7 @@ __device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, doub
             const int t = min(t0 + u * BS, count - 1), sl = t / UPR;
             v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
         }
+        pin_loaded<U>(v);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = t0 + u * BS, sl = t / UPR;

@@ -260,10 +260,13 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const int lane = threadIdx.x & 63;
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
     auto w_of = [&](double q) {
-        return TAB ? table_knots(lds_w, q, inv_dq) : knot_knots([&](int k) { return w_knot(k, pc.dq); }, q, inv_dq);
+        const double t = knot_coord(q, inv_dq);
+        return TAB ? table_knots_at(lds_w, t) : knot_knots_at([&](int k) { return w_knot(k, pc.dq, pc.nq); }, t);
     };
+    // slot tcap of the tile: the sentinel, far away and massless -- what an idle lane visits instead of being masked
+    if (threadIdx.x == 0) tile[tcap] = make_double4(SENTINEL_POS, SENTINEL_POS, SENTINEL_POS, 0.0);
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
     if (group < g_hi) load_plan(plan, group, tm_next);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
         if (fits && kmax > 0) {
             int4 qa = load_row(mine4);
             int4 qb = load_row(mine4 + (size_t)min(1, nrow - 1) * 64);
-            double4 p1 = tile[0 < cnt ? em(half_entry(qa.x, 0)) : 0];
+            double4 p1 = tile[0 < cnt ? em(half_entry(qa.x, 0)) : tcap];
             for (int r = 0; r < nrow; r++) {
                 const int4 qc = load_row(mine4 + (size_t)min(r + 2, nrow - 1) * 64);
 #pragma unroll 1
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                     for (int v = 0; v < 4; v++) {             // whole halves, no trip-count test: the trips past the wave's
                         const int k = 8 * r + 4 * hh + v;     // longest list are masked like any idle lane
                         const double4 pj = p1;
-                        const int s1 = k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : 0;
-                        density_visit_fn(pi, pj, k < cnt, w_of, inv_h, acc, [&]() { p1 = tile[s1]; });     // the next record: behind the knots
+                        const int s1 = k + 1 < cnt ? em(v < 3 ? half_entry(comp4(qa, v + 1), sh) : nxt) : tcap;
+                        density_visit_fn<false>(pi, pj, true, w_of, inv_h, acc, [&]() { p1 = tile[s1]; });     // the next record: behind the knots
                     }
                 }
                 qa = qb; qb = qc;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                 qa = qb; qb = qc;
             }
         }
-        if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq), u, alpha, vx, vy, vz, rho, P, cs, frec);
+        if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq, pc.nq), u, alpha, vx, vy, vz, rho, P, cs, frec);
     }
 }
 
@@ -391,10 +394,18 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     // groups of that eighth in turn
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
-    const double inv_h = 1.0 / pc.h, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
     auto dw_of = [&](double q) {
-        return TAB ? table_knots(lds_dw, q, inv_dq) : knot_knots([&](int k) { return dw_knot(k, pc.dq); }, q, inv_dq);
+        const double t = knot_coord(q, inv_dq);
+        return TAB ? table_knots_at(lds_dw, t) : knot_knots_at([&](int k) { return dw_knot(k, pc.dq, pc.nq); }, t);
     };
+    // slot tcap of the tile: the sentinel record (far away, massless, rho/2 = 1) of the idle lanes; the sums of the epilogue use
+    // the first bytes of the tile only
+    if (threadIdx.x == 0) {
+        double2 *sp = tile + q_unit(tcap);
+        sp[0] = make_double2(SENTINEL_POS, SENTINEL_POS); sp[1] = make_double2(SENTINEL_POS, 0.0); sp[2] = make_double2(0.0, 0.0);
+        sp[3] = make_double2(0.0, 1.0); sp[4] = make_double2(0.0, 0.0); sp[5] = make_double2(0.0, 0.0);
+    }
     // what does not need the tile is fetched one group ahead: the plan and the dealt target of this thread
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                     em.a2 = (int)((unsigned)em.a2 + (unsigned)tm.base[2] - (unsigned)tm.lo[2]);
                 }
                 auto slot_of = [&](int e) { return LPT == 4 ? e : em(e); };       // LPT = 4: an entry IS the slot
-                const double2 *rp = tile + q_unit(sub < cnt ? slot_of(ent_of(wa, 0)) : 0);
+                const double2 *rp = q_record(tile, sub < cnt ? slot_of(ent_of(wa, 0)) : tcap);
                 double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
                 for (int r = 0; r < nrow; r++) {
                     const uint32_t wc = lp[(size_t)min(r + 2, nrow - 1) * 256];
@@ -462,11 +473,11 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                         const Nbr nb{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y, r5.x};
                         const int k = LPT * (TPR * r + hf) + sub;
                         const int en = (TPR == 2 && hf == 0) ? ent_of(wa, 1) : ent_of(wb, 0);
-                        rp = tile + q_unit(k + LPT < cnt ? slot_of(en) : 0);
+                        rp = q_record(tile, k + LPT < cnt ? slot_of(en) : tcap);
                         // the next record is read behind this visit's two table knots: the LDS answers a wave in order, and the
                         // knots are what the visit waits for
-                        force_visit(pc, inv_h, A, B, Cc, nb, k < cnt, dw_of, f,
-                                    [&]() { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5]; });
+                        force_visit<false>(pc, inv_h, A, B, Cc, nb, true, dw_of, f,
+                                           [&]() { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4]; r5 = rp[5]; });
                     }
                     wa = wb; wb = wc;
                 }
@@ -593,7 +604,7 @@ constexpr int FQ_T = 256;            // forces_q: targets per group
 int32_t tile_cap(int nq, int rec, bool tablds) {
     const size_t tab = tablds ? (size_t)(TAB_LDS(nq)) * sizeof(double) : 0;
     if (tab + LDS_RESERVE >= (size_t)LDS_BYTES) return 0;
-    return (int32_t)(((size_t)LDS_BYTES - LDS_RESERVE - tab) / ((size_t)rec * sizeof(double)));
+    return (int32_t)(((size_t)LDS_BYTES - LDS_RESERVE - tab) / ((size_t)rec * sizeof(double))) - 1;      // slot tcap: the sentinel record
 }
 
 // forces_q: 6 units of 16 bytes per record + 1 per eight records
@@ -601,7 +612,7 @@ int32_t tile_cap_q(int nq, bool tablds = true) {
     const size_t tab = tablds ? (size_t)(TAB_LDS(nq)) * sizeof(double) : 0;
     constexpr size_t reserve = 4096;            // static LDS of forces_q
     if (tab + reserve + 64 >= (size_t)LDS_BYTES) return 0;
-    const size_t units = ((size_t)LDS_BYTES - reserve - tab) / 16 - 2;
+    const size_t units = ((size_t)LDS_BYTES - reserve - tab) / 16 - 8;       // the sentinel record at q_unit(tcap): 6 units
     return (int32_t)((units * 8) / 49);
 }
 
@@ -742,7 +753,7 @@ static unsigned persistent_grid(const sph_ctx *c, int64_t ngroups) {
 template <bool TAB>
 static hipError_t density_wt_launch(sph_ctx *c, const PairConst &pc) {
     const int32_t tcap = tile_cap(pc.nq, 4, TAB);
-    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + (size_t)tcap * sizeof(double4);
+    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + ((size_t)tcap + 1) * sizeof(double4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&density_wt<WT_BS, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int64_t ngroups = (c->n + WT_BS - 1) / WT_BS;
@@ -763,7 +774,7 @@ template <int LPT, bool TAB>
 static hipError_t forces_q_launch(sph_ctx *c, const PairConst &pc, int part) {
     constexpr int BS = 1024;
     const int32_t tcap = tile_cap_q(pc.nq, TAB);
-    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 2) * sizeof(double2);
+    const size_t lds = (TAB ? (size_t)(TAB_LDS(pc.nq)) * sizeof(double) : 0) + ((size_t)tcap * 6 + (tcap >> 3) + 8) * sizeof(double2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&forces_q<BS, LPT, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     constexpr int T = BS / LPT;

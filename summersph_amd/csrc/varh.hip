@@ -656,7 +656,7 @@ __global__ __launch_bounds__(VBLOCK) void density_v_kernel(PairConst pc, const d
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
-    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / hi, inv_dq = 0.5 * pc.nq;
 
     // list rows as int4 (four entries), streamed two rows ahead with wave-uniform loads: a quarter of the list
     // instructions of a per-entry read, and the rows do not displace the gather records from the caches
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(VBLOCK) void reflag_density_kernel(PairConst pc, co
     const int oi = number ? number[orig[self]] : orig[self];
     const double hi = pi.w;
     const double ri2 = 4.0 * hi * hi * (1.0 + 1e-12);
-    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq;
+    const double inv_h = 1.0 / hi, inv_dq = 0.5 * pc.nq;
     const int cap4 = cap >> 2;
     int4 *mine = reinterpret_cast<int4 *>(nlist) + ((size_t)w * cap4) * 64 + lane;
     const int cnt_a = live ? min(ncount[i], cap) : 0, tcnt_a = live ? ntail[i] : 0;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
     const int kmax = __builtin_amdgcn_readfirstlane(wave_max[w]);
     const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 2)) * 64 + lane;
     const double hi = Cc.w;
-    const double inv_h = 1.0 / hi, inv_dq = 1.0 / pc.dq, inv_pi = 1.0 / pc.kernel_pi;
+    const double inv_h = 1.0 / hi, inv_dq = 0.5 * pc.nq, inv_pi = 1.0 / pc.kernel_pi;
     const double inv_n4i = 1.0 / (pc.kernel_pi * ((hi * hi) * (hi * hi)));          // [V]:140 for h_i
 
     ForceSums f;
