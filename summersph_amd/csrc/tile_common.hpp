@@ -100,14 +100,47 @@ __device__ __forceinline__ void pin_loaded(double2 (&v)[U]) {
                           "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
 }
 
-template <int BS, int U, int UPR, bool SWZ>
-__device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+// Staging in three parts, so that a kernel can have EVERY global load of a group in flight together -- the tile and what its
+// threads need besides (their target's record, their first list rows): stage_issue sends the first U loads of the thread,
+// stage_wait waits for them (pin_loaded: put it BEFORE the barrier that frees the tile -- the
+// compiler moves loads whose values are first used behind a barrier to behind that barrier), stage_commit writes them to the tile, stage_rest does the trips beyond the first (none when
+// UPR * need <= U * BS, which holds for the kernels with the table in LDS).
+template <int U>
+struct StageRegs { double2 v[U]; };
+
+template <int BS, int U, int UPR>
+__device__ __forceinline__ void stage_issue(StageRegs<U> &st, const double2 *__restrict__ src, const TileMap &tm) {
     const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
     const int count = UPR * tm.need;
-    for (int t0 = threadIdx.x; t0 < count; t0 += U * BS) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {                                  // unconditional (clamped) loads: plain registers
+        const int t = min((int)threadIdx.x + u * BS, count - 1), sl = t / UPR;
+        st.v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
+    }
+}
+template <int U>
+__device__ __forceinline__ void stage_wait(StageRegs<U> &st) { pin_loaded<U>(st.v); }
+template <int BS, int U, int UPR, bool SWZ>
+__device__ __forceinline__ void stage_commit(StageRegs<U> &st, double2 *dst, const TileMap &tm) {
+    const int count = UPR * tm.need;
+    // the thread's U tile addresses depend on threadIdx only: hoisted out of the kernel's group loop they cost U registers for the
+    // whole kernel (spilled, and reloaded one by one here, in round 3) -- the opaque copy keeps their computation in place
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = tid + u * BS, sl = t / UPR;
+        if (t < count) dst[SWZ ? UPR * sl + (sl >> 3) + (t - UPR * sl) : t] = st.v[u];          // UPR = 6: q_unit(sl) + part
+    }
+}
+template <int BS, int U, int UPR, bool SWZ>
+__device__ __forceinline__ void stage_rest(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+    const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
+    const int count = UPR * tm.need;
+    for (int t0 = threadIdx.x + U * BS; t0 < count; t0 += U * BS) {
         double2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {                              // unconditional (clamped) loads: plain registers
+        for (int u = 0; u < U; u++) {
             const int t = min(t0 + u * BS, count - 1), sl = t / UPR;
             v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
         }
@@ -115,9 +148,23 @@ __device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, doub
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = t0 + u * BS, sl = t / UPR;
-            if (t < count) dst[SWZ ? UPR * sl + (sl >> 3) + (t - UPR * sl) : t] = v[u];      // UPR = 6: q_unit(sl) + part
+            if (t < count) dst[SWZ ? UPR * sl + (sl >> 3) + (t - UPR * sl) : t] = v[u];
         }
     }
 }
+template <int BS, int U, int UPR, bool SWZ>
+__device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+    StageRegs<U> st;
+    stage_issue<BS, U, UPR>(st, src, tm);
+    stage_wait<U>(st);
+    stage_commit<BS, U, UPR, SWZ>(st, dst, tm);
+    stage_rest<BS, U, UPR, SWZ>(src, dst, tm);
+}
+
+// values loaded from global memory, pinned like the staged ones: the loads are issued before this point and waited for here
+__device__ __forceinline__ void pin_value(double4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+__device__ __forceinline__ void pin_value(int4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+__device__ __forceinline__ void pin_value(uint32_t &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin_value(int &a) { asm volatile("" : "+v"(a)); }
 
 }  // namespace sph

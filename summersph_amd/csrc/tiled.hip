@@ -33,6 +33,18 @@ constexpr int TB = 256;              // neighbour-list build: threads (= targets
 constexpr int T_NL = 512;            // ... and staged records per chunk (32 B each)
 constexpr int DEAL_BINS = 1024;      // counting sort of a group's list lengths (longer lists share the last bin)
 constexpr int WT_BS = 1024;          // density_wt: threads (= targets) per workgroup, one workgroup per CU
+// -DSPH_PHASE_CLOCKS (profiles/phase_clocks.sh builds it beside the product library): forces_q / density_wt add up, per phase of
+// a group, the ticks of the constant 100-MHz counter -- [0] groups, [1] top of the trip to the tile staged and synchronised,
+// [2] the pair loop of wave 0 (the longest lists), [3] the pair loops of all waves, [4] the waves counted in [3], [5] reduction,
+// epilogue and stores; +8: the same for density_wt
+#ifdef SPH_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clocks[16];
+#define PHASE_NOW() __builtin_readcyclecounter()
+#define PHASE_ADD(slot, v) atomicAdd(&g_phase_clocks[slot], (unsigned long long)(v))
+#else
+#define PHASE_NOW() 0ull
+#define PHASE_ADD(slot, v) ((void)0)
+#endif
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int LDS_RESERVE = 1024;    // static LDS of the kernels (interval scratch) + slack
 
@@ -270,13 +282,17 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
     TileMap tm_next;
     if (group < g_hi) load_plan(plan, group, tm_next);
+#ifdef SPH_PHASE_CLOCKS
+    unsigned long long pa_n = 0, pa_stage = 0, pa_pairs = 0, pa_epi = 0;
+#endif
     for (; group < g_hi; group += per) {
         const TileMap tm = tm_next;
         if (group + per < g_hi) load_plan(plan, group + per, tm_next);
         const int64_t i = group * BS + threadIdx.x;
         const bool fits = tm.need <= tcap;                 // workgroup-uniform
+        const unsigned long long ph0 = PHASE_NOW();
         __syncthreads();                                   // the previous group's tile is no longer read (first trip: the table is written)
-        if (fits) stage_tile<BS, 4, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
+        if (fits) stage_tile<BS, 8, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
         const int64_t w = i >> 6;
         const bool live = i < n && orig[i] < n_owned;
         const int self = i < n ? (int)i : (int)(n - 1);
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
             em.a2 = (int)((unsigned)em.a2 + (unsigned)tm.base[2] - (unsigned)tm.lo[2]);
         }
         __syncthreads();
+        const unsigned long long ph1 = PHASE_NOW();
         double acc = 0.0;
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 3)) * 64 + lane;
         const int nrow = (kmax + 7) >> 3;
@@ -340,8 +357,16 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                 qa = qb; qb = qc;
             }
         }
+        const unsigned long long ph2 = PHASE_NOW();
         if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq, pc.nq), u, alpha, vx, vy, vz, rho, P, cs, frec);
+#ifdef SPH_PHASE_CLOCKS
+        pa_n++; pa_stage += ph1 - ph0; pa_pairs += ph2 - ph1; pa_epi += PHASE_NOW() - ph2;
+#endif
     }
+#ifdef SPH_PHASE_CLOCKS
+    if ((threadIdx.x & 63) == 0) { PHASE_ADD(8 + 3, pa_pairs); PHASE_ADD(8 + 4, pa_n); }
+    if (threadIdx.x == 0) { PHASE_ADD(8 + 0, pa_n); PHASE_ADD(8 + 1, pa_stage); PHASE_ADD(8 + 2, pa_pairs); PHASE_ADD(8 + 5, pa_epi); }
+#endif
 }
 
 // forces, LPT lanes per target.  A workgroup of BS threads owns BS / LPT consecutive targets; the LPT lanes of a target take
@@ -414,6 +439,9 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         load_plan(plan, group, tm_next);
         deal_next = dealt(group);
     }
+#ifdef SPH_PHASE_CLOCKS
+    unsigned long long pa_n = 0, pa_stage = 0, pa_pairs = 0, pa_epi = 0;
+#endif
     for (; group < g_hi; group += per) {
         const int64_t base = group * T;
         const TileMap tm = tm_next;
@@ -429,8 +457,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
             if (!any) continue;
         }
         const bool fits = tm.need <= tcap;
-        __syncthreads();                        // the previous group's tile and sums are no longer read
-        if (fits) stage_tile<BS, 6, 6, true>(reinterpret_cast<const double2 *>(frec), tile, tm);       // every load of the tile in flight at once
+        const unsigned long long ph0 = PHASE_NOW();
         // Targets are dealt to the waves in order of list length (deal_kernel, longest first): a wave's trip count is that
         // of its longest list, and 16 consecutive particles of a disc column span midplane and surface (mean 12 rows,
         // longest of 16: 19).  With every neighbour record in the tile the order costs nothing but the coalescing of the list
@@ -438,20 +465,34 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const int64_t i = base + dl.x;
         const bool live = dl.y >= 0 && (!wave_class || wave_class[i >> 6] == want);
         const int self = i < n ? (int)i : (int)(n - 1);
-        const double4 A = fg[(size_t)self * 3], B = fg[(size_t)self * 3 + 1], Cc = fg[(size_t)self * 3 + 2];
         const int cnt = live ? dl.y : 0;
-        __syncthreads();
         // a trip = LPT consecutive entries of the target's list, one per lane.  LPT = 4: lane s reads word s of the list row (eight
         // 16-bit entries), its low half in the even trip, its high half in the odd one; LPT = 8: lane s reads word s & 3 and
         // takes half s >> 2, a row per trip (ent_pos, tile_common.hpp)
         const int ntrip = __builtin_amdgcn_readfirstlane(wave_max_i32((cnt + LPT - 1) / LPT));
-        ForceSums f;
+        const int nrow = (ntrip + TPR - 1) / TPR;
         const uint32_t *lp = reinterpret_cast<const uint32_t *>(nlist) + (((size_t)(self >> 6) * (cap >> 3)) * 64 + (self & 63)) * 4 + (sub & 3);
+        // the first two list rows are asked for ahead of the tile; the target's record is read from the tile: one round trip to
+        // memory for the tile where there were four (tile in two trips, then the record, then the rows)
+        uint32_t wa = lp[0];
+        uint32_t wb = lp[(size_t)min(1, max(nrow, 1) - 1) * 256];
+        pin_value(wa); pin_value(wb);           // (asked for before the barrier: the compiler would move the loads to their first use)
+        __syncthreads();                        // the previous group's tile and sums are no longer read
+        if (fits) stage_tile<BS, 8, 6, true>(reinterpret_cast<const double2 *>(frec), tile, tm);       // every load of the tile in flight at once
+        __syncthreads();
+        // the target's own record: it is in the tile (its cell is one of its neighbour cells) -- an LDS read, not a third trip to memory
+        double4 A, B, Cc;
+        if (fits) {
+            const double2 *sp = q_record(tile, tm.slot(self));
+            const double2 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
+            A = make_double4(s0.x, s0.y, s1.x, s1.y); B = make_double4(s2.x, s2.y, s3.x, s3.y); Cc = make_double4(s4.x, s4.y, s5.x, s5.y);
+        } else {
+            A = fg[(size_t)self * 3]; B = fg[(size_t)self * 3 + 1]; Cc = fg[(size_t)self * 3 + 2];
+        }
+        const unsigned long long ph1 = PHASE_NOW();
+        ForceSums f;
         auto ent_of = [&](uint32_t wd, int hf) { return (int)((wd >> ((LPT == 4 ? hf : (sub >> 2)) << 4)) & 0xffffu); };
         if (ntrip > 0) {
-            const int nrow = (ntrip + TPR - 1) / TPR;
-            uint32_t wa = lp[0];
-            uint32_t wb = lp[(size_t)min(1, nrow - 1) * 256];
             // entries are slots of the 256-group's tile (LPT = 4: this tile) or, plus a constant per interval, of this half group's
             // tile / the sorted order
             if (fits) {
@@ -500,6 +541,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                 }
             }
         }
+        const unsigned long long ph2 = PHASE_NOW();
         // the target's sums, added in a fixed tree over its LPT lanes: the same value in all of them
 #pragma unroll
         for (int o = 1; o < LPT; o <<= 1) {
@@ -525,7 +567,14 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
             ft.s0 = s_sum[0 * T + t]; ft.s1 = s_sum[1 * T + t]; ft.s2 = s_sum[2 * T + t]; ft.sdu = s_sum[3 * T + t]; ft.sdal = s_sum[4 * T + t];
             force_epilogue(pc, sink, s_tgt[t], At, Bt, Ct, ft, ax, ay, az, du, dalpha);
         }
+#ifdef SPH_PHASE_CLOCKS
+        pa_n++; pa_stage += ph1 - ph0; pa_pairs += ph2 - ph1; pa_epi += PHASE_NOW() - ph2;
+#endif
     }
+#ifdef SPH_PHASE_CLOCKS
+    if ((threadIdx.x & 63) == 0) { PHASE_ADD(3, pa_pairs); PHASE_ADD(4, pa_n); }
+    if (threadIdx.x == 0) { PHASE_ADD(0, pa_n); PHASE_ADD(1, pa_stage); PHASE_ADD(2, pa_pairs); PHASE_ADD(5, pa_epi); }
+#endif
 }
 
 
@@ -796,3 +845,12 @@ hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
 }
 
 }  // namespace sph
+
+#ifdef SPH_PHASE_CLOCKS
+// profiling build only: read (and clear) the phase counters
+extern "C" int sph_debug_phase_clocks(unsigned long long *out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sph::g_phase_clocks), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(sph::g_phase_clocks), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
