@@ -298,18 +298,52 @@ __device__ __forceinline__ void sink_gas_accel(const PairConst &pc, const double
     }
 }
 
-// rates of particle i from its sums (fixed h): sink gravity, normalisation, the alpha rate of [F]:316-318
-// (rho_i = 2 B.w, c_i = 2 C.x, alpha_i = 2 C.y: exact)
-__device__ __forceinline__ void force_epilogue(const PairConst &pc, const double *__restrict__ sink, int64_t i, const double4 &A,
+// ---- rates of particle i from its sums (fixed h): sink gravity, normalisation, the alpha rate of [F]:316-318 -------------
+// (rho_i = 2 B.w, c_i = 2 C.x, alpha_i = 2 C.y: exact).  Written per CHANNEL -- 0, 1, 2: the acceleration components, 3: du/dt --
+// so that the whole-tile kernel can give the four channels of a target to the four lanes that summed it, each storing its
+// own; the gather kernels evaluate the four channels in one thread (the compiler shares what they have in common).  No IEEE
+// division or square root (~30 instructions each): the hardware seeds refined to ~1 ulp, as in the pair terms.
+struct SinkRows { const double *x, *y, *z, *m; };          // positions and masses of the sinks: MAX_SINKS doubles each, global or LDS
+__device__ __forceinline__ SinkRows sink_rows(const double *sink) {
+    return SinkRows{sink, sink + MAX_SINKS, sink + 2 * MAX_SINKS, sink + 6 * MAX_SINKS};
+}
+
+// acc_in: the channel's start value -- zero_rates [+ the self-gravity term already in ax..az, [F]:824-825] (channel 3: unused)
+__device__ __forceinline__ double force_channel(const PairConst &pc, const SinkRows &sk, const double4 &A, const ForceSums &f,
+                                                double acc_in, int c) {
+#pragma clang fp contract(off)
+    const double sum_c = c == 0 ? f.s0 : (c == 1 ? f.s1 : f.s2);
+    double a = acc_in;
+    for (int s = 0; s < pc.ns; s++) {                                             // the gas side of sink_gravforces, [F]:567-576
+        const double v0 = A.x - sk.x[s], v1 = A.y - sk.y[s], v2 = A.z - sk.z[s];
+        const double vc = c == 0 ? v0 : (c == 1 ? v1 : v2);
+        double dr, rs;
+        rsqrt_sqrt(fma(v2, v2, fma(v1, v1, v0 * v0)), dr, rs);
+        const double gm = (sk.m[s] * pc.G) * ((rs * rs) * rs);                    // G m_s / dr^3
+        a = fma(-gm, vc, a);
+    }
+    const double acc = a - sum_c * pc.inv_dwnorm;                                 // [F]:383; [F]:126 applied once
+    return c == 3 ? f.sdu * pc.inv_dwnorm : acc;                                  // [F]:387
+}
+// the alpha rate, [F]:316-318,390
+__device__ __forceinline__ double alpha_rate(const PairConst &pc, double inv_h, double rho_half, double c_half, double al_half,
+                                             const ForceSums &f) {
+#pragma clang fp contract(off)
+    return fmax((f.sdal * pc.inv_dwnorm) * fast_rcp(2.0 * rho_half), 0.0) +
+           pc.alpha_decay * (((pc.alpha_floor - 2.0 * al_half) * (2.0 * c_half)) * inv_h);
+}
+
+__device__ __forceinline__ void force_epilogue(const PairConst &pc, const double *__restrict__ sink, int64_t i, double inv_h, const double4 &A,
                                                const double4 &B, const double4 &C, const ForceSums &f, double *__restrict__ ax,
                                                double *__restrict__ ay, double *__restrict__ az, double *__restrict__ du,
                                                double *__restrict__ dalpha) {
-    double a0, a1, a2;
-    sink_gas_accel(pc, sink, A, i, ax, ay, az, a0, a1, a2);
-    const double inv_dwn = 1.0 / pc.dwnorm;                                       // [F]:126, applied once
-    ax[i] = a0 - f.s0 * inv_dwn; ay[i] = a1 - f.s1 * inv_dwn; az[i] = a2 - f.s2 * inv_dwn;
-    du[i] = f.sdu * inv_dwn;
-    dalpha[i] = fmax((f.sdal * inv_dwn) / (2.0 * B.w), 0.0) + pc.alpha_decay * ((pc.alpha_floor - 2.0 * C.y) * (2.0 * C.x) / pc.h);
+    const SinkRows sk = sink_rows(sink);
+    const double a0 = pc.grav ? ax[i] : 0.0, a1 = pc.grav ? ay[i] : 0.0, a2 = pc.grav ? az[i] : 0.0;
+    ax[i] = force_channel(pc, sk, A, f, a0, 0);
+    ay[i] = force_channel(pc, sk, A, f, a1, 1);
+    az[i] = force_channel(pc, sk, A, f, a2, 2);
+    du[i] = force_channel(pc, sk, A, f, 0.0, 3);
+    dalpha[i] = alpha_rate(pc, inv_h, B.w, C.x, C.y, f);
 }
 
 }  // namespace sph

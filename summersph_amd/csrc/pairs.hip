@@ -257,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
         force_visit(pc, inv_h, A, B, Cc, nb, act, dw_of, f);
     }
     if (!live) return;
-    force_epilogue(pc, sink, i, A, B, Cc, f, ax, ay, az, du, dalpha);
+    force_epilogue(pc, sink, i, inv_h, A, B, Cc, f, ax, ay, az, du, dalpha);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,7 +336,7 @@ PairConst make_pair_const(const sph_ctx *c) {
     pc.nq = p.nq;
     pc.dq = 2.0 / p.nq;                                   // [F]:10
     pc.wnorm = p.kernel_pi * (p.h * p.h * p.h);           // [F]:125
-    pc.dwnorm = p.kernel_pi * (p.h * p.h * p.h * p.h);    // [F]:126
+    pc.inv_dwnorm = 1.0 / (p.kernel_pi * (p.h * p.h * p.h * p.h));    // [F]:126
     pc.visc_eps_h2 = p.visc_eps * p.h * p.h;              // [F]:373
     pc.alpha_floor = p.alpha_floor; pc.alpha_decay = p.alpha_decay;
     pc.G = p.G; pc.gamma = p.gamma; pc.gamma_m1 = p.gamma_m1;

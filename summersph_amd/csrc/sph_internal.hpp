@@ -39,7 +39,7 @@ struct PairConst {
     double h;            // smoothing length
     double dq;           // 2/nq
     double wnorm;        // kernel_pi * h^3        (W  is DIVIDED by this, [F]:125)
-    double dwnorm;       // kernel_pi * h^4        (dW is DIVIDED by this, [F]:126)
+    double inv_dwnorm;   // 1 / (kernel_pi * h^4)  (dW is divided by kernel_pi h^4, [F]:126: once, in the epilogue)
     double visc_eps_h2;  // (0.01f * h) * h        ([F]:373)
     double alpha_floor, alpha_decay, G, gamma, gamma_m1;
     double rcut2;        // (2h)^2 (1 + 1e-12): filter only, the evaluation re-tests q <= 2

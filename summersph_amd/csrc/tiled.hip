@@ -38,12 +38,17 @@ constexpr int WT_BS = 1024;          // density_wt: threads (= targets) per work
 // [2] the pair loop of wave 0 (the longest lists), [3] the pair loops of all waves, [4] the waves counted in [3], [5] reduction,
 // epilogue and stores; +8: the same for density_wt
 #ifdef SPH_PHASE_CLOCKS
-__device__ unsigned long long g_phase_clocks[16];
+__device__ unsigned long long g_phase_clocks[64];
 #define PHASE_NOW() __builtin_readcyclecounter()
 #define PHASE_ADD(slot, v) atomicAdd(&g_phase_clocks[slot], (unsigned long long)(v))
+// forces_q, finer: PH_MARK(k) adds the ticks since the previous mark to phase k of wave 0 (an epilogue wave; [32 + k]) and of
+// the last wave (a stager; [48 + k]), collected in LDS and added to g_phase_clocks once per workgroup
+#define PH_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (ph_sel >= 0 && (threadIdx.x & 63) == 0) atomicAdd(&s_phase[ph_sel][k], now_ - ph_last); ph_last = now_; } while (0)
 #else
 #define PHASE_NOW() 0ull
 #define PHASE_ADD(slot, v) ((void)0)
+#define PH_MARK(k) ((void)0)
 #endif
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int LDS_RESERVE = 1024;    // static LDS of the kernels (interval scratch) + slack
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
         if (group + per < g_hi) load_plan(plan, group + per, tm_next);
         const int64_t i = group * BS + threadIdx.x;
         const bool fits = tm.need <= tcap;                 // workgroup-uniform
-        const unsigned long long ph0 = PHASE_NOW();
+        [[maybe_unused]] const unsigned long long ph0 = PHASE_NOW();
         __syncthreads();                                   // the previous group's tile is no longer read (first trip: the table is written)
         if (fits) stage_tile<BS, 8, 2, false>(reinterpret_cast<const double2 *>(drec), reinterpret_cast<double2 *>(tile), tm);
         const int64_t w = i >> 6;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
             em.a2 = (int)((unsigned)em.a2 + (unsigned)tm.base[2] - (unsigned)tm.lo[2]);
         }
         __syncthreads();
-        const unsigned long long ph1 = PHASE_NOW();
+        [[maybe_unused]] const unsigned long long ph1 = PHASE_NOW();
         double acc = 0.0;
         const int4 *mine4 = reinterpret_cast<const int4 *>(nlist) + ((size_t)w * (cap >> 3)) * 64 + lane;
         const int nrow = (kmax + 7) >> 3;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                 qa = qb; qb = qc;
             }
         }
-        const unsigned long long ph2 = PHASE_NOW();
+        [[maybe_unused]] const unsigned long long ph2 = PHASE_NOW();
         if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq, pc.nq), u, alpha, vx, vy, vz, rho, P, cs, frec);
 #ifdef SPH_PHASE_CLOCKS
         pa_n++; pa_stage += ph1 - ph0; pa_pairs += ph2 - ph1; pa_epi += PHASE_NOW() - ph2;
@@ -400,11 +405,16 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     extern __shared__ double lds_dyn[];
     double *lds_dw = lds_dyn;
     double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? (TAB_LDS(pc.nq)) : 0));      // !TAB: dW knots recomputed (density_wt)
-    __shared__ int s_tgt[T];
+    __shared__ double s_sink[4][MAX_SINKS];              // x, y, z, m of the sinks: the epilogue reads them here, not through serial scalar loads
     const int sub = threadIdx.x & (LPT - 1), tl = threadIdx.x / LPT;
     const double4 *fg = reinterpret_cast<const double4 *>(frec);
+    // Waves w, w + 4, w + 8, w + 12 share a SIMD, and the deal hands out the targets longest list first, sixteen per wave: taken in
+    // wave order SIMD 0 would get the longest sixteen of every quarter (19 % more trips than SIMD 3 for lists of 70 down to 25),
+    // and the group lasts as long as its slowest SIMD.  Every second row of four waves takes its chunks in reverse.
+    const int wv = threadIdx.x >> 6, chunk = (wv & 4) ? (wv ^ 3) : wv;
+    const int rank = LPT == 4 ? chunk * 16 + (tl & 15) : tl;
     auto dealt = [&](int64_t g) -> int2 {                  // this thread's target in group g: {index within the group, list length or -1}
-        const int64_t t = g * T + tl;
+        const int64_t t = g * T + rank;
         if (t >= n) return make_int2(0, -1);
         if (LPT == 4) return deal[t];
         return make_int2(tl, orig[t] < n_owned ? min(ncount[t], cap) : -1);
@@ -424,8 +434,12 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         const double t = knot_coord(q, inv_dq);
         return TAB ? table_knots_at(lds_dw, t) : knot_knots_at([&](int k) { return dw_knot(k, pc.dq, pc.nq); }, t);
     };
-    // slot tcap of the tile: the sentinel record (far away, massless, rho/2 = 1) of the idle lanes; the sums of the epilogue use
-    // the first bytes of the tile only
+    if (threadIdx.x < 4 * MAX_SINKS) {
+        const int row = threadIdx.x / MAX_SINKS, s = threadIdx.x % MAX_SINKS;
+        s_sink[row][s] = s < pc.ns ? sink[(row == 3 ? 6 : row) * MAX_SINKS + s] : 0.0;
+    }
+    const SinkRows sk{s_sink[0], s_sink[1], s_sink[2], s_sink[3]};
+    // slot tcap of the tile: the sentinel record (far away, massless, rho/2 = 1) of the idle lanes
     if (threadIdx.x == 0) {
         double2 *sp = tile + q_unit(tcap);
         sp[0] = make_double2(SENTINEL_POS, SENTINEL_POS); sp[1] = make_double2(SENTINEL_POS, 0.0); sp[2] = make_double2(0.0, 0.0);
@@ -440,7 +454,11 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         deal_next = dealt(group);
     }
 #ifdef SPH_PHASE_CLOCKS
-    unsigned long long pa_n = 0, pa_stage = 0, pa_pairs = 0, pa_epi = 0;
+    unsigned long long pa_n = 0;
+    __shared__ unsigned long long s_phase[2][16];
+    if (threadIdx.x < 32) s_phase[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+    const int ph_sel = (threadIdx.x >> 6) == 0 ? 0 : ((threadIdx.x >> 6) == BS / 64 - 1 ? 1 : -1);
+    unsigned long long ph_last = __builtin_readcyclecounter();
 #endif
     for (; group < g_hi; group += per) {
         const int64_t base = group * T;
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
             if (!any) continue;
         }
         const bool fits = tm.need <= tcap;
-        const unsigned long long ph0 = PHASE_NOW();
+        PH_MARK(0);      // end of the previous trip (epilogue, prefetches) .. top
         // Targets are dealt to the waves in order of list length (deal_kernel, longest first): a wave's trip count is that
         // of its longest list, and 16 consecutive particles of a disc column span midplane and surface (mean 12 rows,
         // longest of 16: 19).  With every neighbour record in the tile the order costs nothing but the coalescing of the list
@@ -477,9 +495,13 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         uint32_t wa = lp[0];
         uint32_t wb = lp[(size_t)min(1, max(nrow, 1) - 1) * 256];
         pin_value(wa); pin_value(wb);           // (asked for before the barrier: the compiler would move the loads to their first use)
+        PH_MARK(1);      // own list rows arrived
         __syncthreads();                        // the previous group's tile and sums are no longer read
+        PH_MARK(2);      // barrier 1
         if (fits) stage_tile<BS, 8, 6, true>(reinterpret_cast<const double2 *>(frec), tile, tm);       // every load of the tile in flight at once
+        PH_MARK(3);      // tile loads + writes
         __syncthreads();
+        PH_MARK(4);      // barrier 2
         // the target's own record: it is in the tile (its cell is one of its neighbour cells) -- an LDS read, not a third trip to memory
         double4 A, B, Cc;
         if (fits) {
@@ -489,7 +511,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         } else {
             A = fg[(size_t)self * 3]; B = fg[(size_t)self * 3 + 1]; Cc = fg[(size_t)self * 3 + 2];
         }
-        const unsigned long long ph1 = PHASE_NOW();
+        PH_MARK(5);      // own record out of the tile
         ForceSums f;
         auto ent_of = [&](uint32_t wd, int hf) { return (int)((wd >> ((LPT == 4 ? hf : (sub >> 2)) << 4)) & 0xffffu); };
         if (ntrip > 0) {
@@ -541,39 +563,34 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
                 }
             }
         }
-        const unsigned long long ph2 = PHASE_NOW();
+        PH_MARK(6);      // pair loop
         // the target's sums, added in a fixed tree over its LPT lanes: the same value in all of them
 #pragma unroll
         for (int o = 1; o < LPT; o <<= 1) {
             f.s0 += __shfl_xor(f.s0, o, 64); f.s1 += __shfl_xor(f.s1, o, 64); f.s2 += __shfl_xor(f.s2, o, 64);
             f.sdu += __shfl_xor(f.sdu, o, 64); f.sdal += __shfl_xor(f.sdal, o, 64);
         }
-        // the epilogue (sink gravity with its IEEE divisions and square root, the stores) by one thread per target instead
-        // of one lane in four of every wave; the sums travel through the first bytes of the tile, which nobody reads any more
-        __syncthreads();
-        double *s_sum = reinterpret_cast<double *>(tile);           // [11][T]
-        if (sub == 0) {
-            s_sum[0 * T + tl] = f.s0; s_sum[1 * T + tl] = f.s1; s_sum[2 * T + tl] = f.s2; s_sum[3 * T + tl] = f.sdu; s_sum[4 * T + tl] = f.sdal;
-            s_sum[5 * T + tl] = A.x; s_sum[6 * T + tl] = A.y; s_sum[7 * T + tl] = A.z; s_sum[8 * T + tl] = B.w; s_sum[9 * T + tl] = Cc.x;
-            s_sum[10 * T + tl] = Cc.y;
-            s_tgt[tl] = live ? (int)i : -1;
-        }
-        __syncthreads();
-        if (threadIdx.x < T && s_tgt[threadIdx.x] >= 0) {
-            const int t = threadIdx.x;
-            const double4 At = make_double4(s_sum[5 * T + t], s_sum[6 * T + t], s_sum[7 * T + t], 0.0), Bt = make_double4(0.0, 0.0, 0.0, s_sum[8 * T + t]),
-                          Ct = make_double4(s_sum[9 * T + t], s_sum[10 * T + t], 0.0, 0.0);
-            ForceSums ft;
-            ft.s0 = s_sum[0 * T + t]; ft.s1 = s_sum[1 * T + t]; ft.s2 = s_sum[2 * T + t]; ft.sdu = s_sum[3 * T + t]; ft.sdal = s_sum[4 * T + t];
-            force_epilogue(pc, sink, s_tgt[t], At, Bt, Ct, ft, ax, ay, az, du, dalpha);
+        PH_MARK(7);      // lane reduction
+        // The epilogue, by the wave itself and at once -- no barrier, no hand-over through LDS: the waves that finish their lists
+        // early (the oldest ones, which the SIMD serves first) do it while the others still walk theirs.  The first four lanes of
+        // a target take one channel each (three acceleration components, du/dt) and store it; what the channels share (the
+        // distance to each sink) is computed by all of them at the cost of one.
+        if (live && sub < 4) {
+            double *const out = sub == 0 ? ax : (sub == 1 ? ay : (sub == 2 ? az : du));
+            const double start = (pc.grav && sub < 3) ? out[i] : 0.0;
+            out[i] = force_channel(pc, sk, A, f, start, sub);
+            if (sub == 3) dalpha[i] = alpha_rate(pc, inv_h, B.w, Cc.x, Cc.y, f);
         }
 #ifdef SPH_PHASE_CLOCKS
-        pa_n++; pa_stage += ph1 - ph0; pa_pairs += ph2 - ph1; pa_epi += PHASE_NOW() - ph2;
+        pa_n++;
+        PH_MARK(8);      // epilogue
 #endif
     }
 #ifdef SPH_PHASE_CLOCKS
-    if ((threadIdx.x & 63) == 0) { PHASE_ADD(3, pa_pairs); PHASE_ADD(4, pa_n); }
-    if (threadIdx.x == 0) { PHASE_ADD(0, pa_n); PHASE_ADD(1, pa_stage); PHASE_ADD(2, pa_pairs); PHASE_ADD(5, pa_epi); }
+    PH_MARK(0);
+    if (threadIdx.x == 0) PHASE_ADD(0, pa_n);
+    __syncthreads();
+    if (threadIdx.x < 32) PHASE_ADD(32 + threadIdx.x, s_phase[threadIdx.x >> 4][threadIdx.x & 15]);
 #endif
 }
 
@@ -848,9 +865,9 @@ hipError_t launch_forces_wt(sph_ctx *c, const PairConst &pc, int part) {
 
 #ifdef SPH_PHASE_CLOCKS
 // profiling build only: read (and clear) the phase counters
-extern "C" int sph_debug_phase_clocks(unsigned long long *out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sph::g_phase_clocks), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long zero[16] = {};
+extern "C" int sph_debug_phase_clocks(unsigned long long *out64) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(sph::g_phase_clocks), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long zero[64] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(sph::g_phase_clocks), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -13,7 +13,7 @@ gas, sinks = ic.split_rows(ic.keplerian_disc(n, seed=214, nngb=85.0))
 ctx = capi.Context(device=0)
 ctx.upload(gas); ctx.set_sinks(sinks)
 dt, t = ctx.run(5, 1e-2, 0.0); ctx.synchronize()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 64)()
 lib.sph_debug_phase_clocks(buf)          # clear
 dt, t = ctx.run(steps, dt, t); ctx.synchronize()
 assert lib.sph_debug_phase_clocks(buf) == 0
@@ -28,4 +28,10 @@ for name, o in (("forces_q", 0), ("density_wt", 8)):
                                   "reduce+epilogue": round(v[o + 5] / g * tick_us, 2)}}
     tot = (v[o + 1] + v[o + 2] + v[o + 5]) / g * tick_us
     out[name]["us_per_group"]["total_wave0"] = round(tot, 2)
-print(json.dumps(out))
+names = ["loop back..top", "own rows", "barrier1", "tile loads+writes", "barrier2", "own record", "pair loop", "lane reduction", "epilogue"]
+g = max(v[0], 1)
+for label, o in (("wave0 (epilogue wave)", 32), ("last wave (stager)", 48)):
+    tot = sum(v[o:o + len(names)]) or 1
+    out["forces_q " + label] = {nm: round(100.0 * v[o + k] / tot, 1) for k, nm in enumerate(names)}
+    out["forces_q " + label]["ticks_per_group"] = round(tot / g, 1)
+print(json.dumps(out, indent=1))
