@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void density_kernel(PairConst pc, const doub
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
-    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
+    const double inv_h = pc.inv_h, inv_dq = pc.inv_dq;
 
     // Software pipeline: neighbour indices are fetched two trips ahead, records one trip ahead, so
     // the dependent index -> record gather chain overlaps the arithmetic of the current pair.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void forces_kernel(PairConst pc, const doubl
     const int cnt = live ? min(ncount[i], cap) : 0;
     const int kmax = wave_max[w];
     const ListColumn<PACKED> mine(nlist, plan_f, w, cap, lane, self);
-    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
+    const double inv_h = pc.inv_h, inv_dq = pc.inv_dq;
 
     ForceSums f;
     auto dw_of = [&](double q) { return table_knots_at(lds_dw, knot_coord(q, inv_dq)); };
@@ -335,6 +335,8 @@ PairConst make_pair_const(const sph_ctx *c) {
     pc.h = p.h;
     pc.nq = p.nq;
     pc.dq = 2.0 / p.nq;                                   // [F]:10
+    pc.inv_h = 1.0 / p.h;
+    pc.inv_dq = 0.5 * p.nq;
     pc.wnorm = p.kernel_pi * (p.h * p.h * p.h);           // [F]:125
     pc.inv_dwnorm = 1.0 / (p.kernel_pi * (p.h * p.h * p.h * p.h));    // [F]:126
     pc.visc_eps_h2 = p.visc_eps * p.h * p.h;              // [F]:373

@@ -37,6 +37,8 @@ struct GridDesc {
 // Constants every pair kernel needs; passed by value as a kernel argument (SGPRs).
 struct PairConst {
     double h;            // smoothing length
+    double inv_h;        // 1 / h
+    double inv_dq;       // nq / 2 exactly (dq = 2 / nq, [F]:58): scalar registers for the kernels, not vector ones computed per thread
     double dq;           // 2/nq
     double wnorm;        // kernel_pi * h^3        (W  is DIVIDED by this, [F]:125)
     double inv_dwnorm;   // 1 / (kernel_pi * h^4)  (dW is divided by kernel_pi h^4, [F]:126: once, in the epilogue)

@@ -89,15 +89,19 @@ __device__ __forceinline__ const double2 *q_record(const double2 *tile, int s) {
 // round 3: global_load, s_waitcnt vmcnt(0), ds_write, U times); with it the U loads are issued back to back and waited for once.
 template <int U>
 __device__ __forceinline__ void pin_loaded(double2 (&v)[U]) {
-    static_assert(U == 4 || U == 6 || U == 8, "stage_tile: 4, 6 or 8 loads in flight");
+    static_assert(U == 4 || U == 6 || U == 8 || U == 10, "stage_tile: 4, 6, 8 or 10 loads in flight");
     if constexpr (U == 4)
         asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y));
     else if constexpr (U == 6)
         asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
                           "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y));
-    else
+    else if constexpr (U == 8)
         asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
                           "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+    else
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+                          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y),
+                          "+v"(v[8].x), "+v"(v[8].y), "+v"(v[9].x), "+v"(v[9].y));
 }
 
 // Staging in three parts, so that a kernel can have EVERY global load of a group in flight together -- the tile and what its
@@ -108,24 +112,27 @@ __device__ __forceinline__ void pin_loaded(double2 (&v)[U]) {
 template <int U>
 struct StageRegs { double2 v[U]; };
 
+// (BS: the threads that stage, me: this thread's number among them -- all of the workgroup by default)
 template <int BS, int U, int UPR>
-__device__ __forceinline__ void stage_issue(StageRegs<U> &st, const double2 *__restrict__ src, const TileMap &tm) {
+__device__ __forceinline__ void stage_issue(StageRegs<U> &st, const double2 *__restrict__ src, const TileMap &tm, int me = threadIdx.x) {
     const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
     const int count = UPR * tm.need;
+    int tid = me;                                                  // opaque, as in stage_commit
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int u = 0; u < U; u++) {                                  // unconditional (clamped) loads: plain registers
-        const int t = min((int)threadIdx.x + u * BS, count - 1), sl = t / UPR;
+        const int t = max(min(tid + u * BS, count - 1), 0), sl = t / UPR;
         st.v[u] = src[(size_t)UPR * (size_t)(sl + (sl >= b2 ? o2 : (sl >= b1 ? o1 : o0))) + (t - UPR * sl)];
     }
 }
 template <int U>
 __device__ __forceinline__ void stage_wait(StageRegs<U> &st) { pin_loaded<U>(st.v); }
 template <int BS, int U, int UPR, bool SWZ>
-__device__ __forceinline__ void stage_commit(StageRegs<U> &st, double2 *dst, const TileMap &tm) {
+__device__ __forceinline__ void stage_commit(StageRegs<U> &st, double2 *dst, const TileMap &tm, int me = threadIdx.x) {
     const int count = UPR * tm.need;
     // the thread's U tile addresses depend on threadIdx only: hoisted out of the kernel's group loop they cost U registers for the
     // whole kernel (spilled, and reloaded one by one here, in round 3) -- the opaque copy keeps their computation in place
-    int tid = threadIdx.x;
+    int tid = me;
     asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -134,10 +141,10 @@ __device__ __forceinline__ void stage_commit(StageRegs<U> &st, double2 *dst, con
     }
 }
 template <int BS, int U, int UPR, bool SWZ>
-__device__ __forceinline__ void stage_rest(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+__device__ __forceinline__ void stage_rest(const double2 *__restrict__ src, double2 *dst, const TileMap &tm, int me = threadIdx.x) {
     const int b1 = tm.base[1], b2 = tm.base[2], o0 = tm.lo[0], o1 = tm.lo[1] - b1, o2 = tm.lo[2] - b2;
     const int count = UPR * tm.need;
-    for (int t0 = threadIdx.x + U * BS; t0 < count; t0 += U * BS) {
+    for (int t0 = me + U * BS; t0 < count; t0 += U * BS) {
         double2 v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -154,6 +161,7 @@ __device__ __forceinline__ void stage_rest(const double2 *__restrict__ src, doub
 }
 template <int BS, int U, int UPR, bool SWZ>
 __device__ __forceinline__ void stage_tile(const double2 *__restrict__ src, double2 *dst, const TileMap &tm) {
+    if (tm.need <= 0) return;         // (a group of ghosts only: nothing to stage, and the clamped loads of stage_issue would start at -1)
     StageRegs<U> st;
     stage_issue<BS, U, UPR>(st, src, tm);
     stage_wait<U>(st);

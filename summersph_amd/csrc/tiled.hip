@@ -33,6 +33,10 @@ constexpr int TB = 256;              // neighbour-list build: threads (= targets
 constexpr int T_NL = 512;            // ... and staged records per chunk (32 B each)
 constexpr int DEAL_BINS = 1024;      // counting sort of a group's list lengths (longer lists share the last bin)
 constexpr int WT_BS = 1024;          // density_wt: threads (= targets) per workgroup, one workgroup per CU
+// the arguments of forces_q / density_wt that only their epilogues read (kept in LDS, see there)
+struct alignas(16) DensEpiArgs { const double *u, *alpha, *vx, *vy, *vz; double *rho, *P, *cs, *frec; double wnorm, gamma, gamma_m1, h; };
+struct alignas(16) EpiArgs { double G, alpha_floor, alpha_decay, inv_dwnorm; double *ax, *ay, *az, *du, *dalpha; int ns, grav; };
+
 // -DSPH_PHASE_CLOCKS (profiles/phase_clocks.sh builds it beside the product library): forces_q / density_wt add up, per phase of
 // a group, the ticks of the constant 100-MHz counter -- [0] groups, [1] top of the trip to the tile staged and synchronised,
 // [2] the pair loop of wave 0 (the longest lists), [3] the pair loops of all waves, [4] the waves counted in [3], [5] reduction,
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
                                                  const double *__restrict__ vy, const double *__restrict__ vz,
                                                  double *__restrict__ rho, double *__restrict__ P, double *__restrict__ cs,
                                                  double *__restrict__ frec, const int32_t *__restrict__ orig, int32_t n_owned) {
-    extern __shared__ double lds_dyn[];
+    extern __shared__ __align__(16) double lds_dyn[];      // (16: the tile is read 16 bytes at a time; static LDS in front of it must not shift it by 8)
     double *lds_w = lds_dyn;                                               // TAB_LEN(nq) doubles (padded to even)
     double4 *tile = reinterpret_cast<double4 *>(lds_dyn + (TAB ? (TAB_LDS(pc.nq)) : 0));
     // persistent, as forces_q: one workgroup per CU walks over groups of BS targets; the table once, the plan one group ahead;
@@ -277,11 +281,14 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
     const int lane = threadIdx.x & 63;
-    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
+    const double inv_h = pc.inv_h, inv_dq = pc.inv_dq;
     auto w_of = [&](double q) {
         const double t = knot_coord(q, inv_dq);
         return TAB ? table_knots_at(lds_w, t) : knot_knots_at([&](int k) { return w_knot(k, pc.dq, pc.nq); }, t);
     };
+    // what only the epilogue needs of the arguments waits in LDS (26 scalar registers less across the pair loop; see forces_q)
+    __shared__ DensEpiArgs s_epi;
+    if (threadIdx.x == 0) s_epi = DensEpiArgs{u, alpha, vx, vy, vz, rho, P, cs, frec, pc.wnorm, pc.gamma, pc.gamma_m1, pc.h};
     // slot tcap of the tile: the sentinel, far away and massless -- what an idle lane visits instead of being masked
     if (threadIdx.x == 0) tile[tcap] = make_double4(SENTINEL_POS, SENTINEL_POS, SENTINEL_POS, 0.0);
     int64_t group = (int64_t)ngroups * xcd / nx + blockIdx.x / nx;
@@ -363,7 +370,12 @@ __global__ __launch_bounds__(BS) void density_wt(PairConst pc, int32_t tcap, int
             }
         }
         [[maybe_unused]] const unsigned long long ph2 = PHASE_NOW();
-        if (live) density_epilogue(pc, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq, pc.nq), u, alpha, vx, vy, vz, rho, P, cs, frec);
+        if (live) {
+            const DensEpiArgs ea = s_epi;
+            PairConst pe;
+            pe.wnorm = ea.wnorm; pe.gamma = ea.gamma; pe.gamma_m1 = ea.gamma_m1; pe.h = ea.h;
+            density_epilogue(pe, i, pi, acc, TAB ? lds_w[0] : w_knot(0, pc.dq, pc.nq), ea.u, ea.alpha, ea.vx, ea.vy, ea.vz, ea.rho, ea.P, ea.cs, ea.frec);
+        }
 #ifdef SPH_PHASE_CLOCKS
         pa_n++; pa_stage += ph1 - ph0; pa_pairs += ph2 - ph1; pa_epi += PHASE_NOW() - ph2;
 #endif
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     static_assert(LPT == 4 || LPT == 8, "a list row holds eight entries: two trips of four lanes or one of eight");
     constexpr int T = BS / LPT;
     constexpr int TPR = 8 / LPT;                           // trips per list row
-    extern __shared__ double lds_dyn[];
+    extern __shared__ __align__(16) double lds_dyn[];      // (16: the tile is read 16 bytes at a time; static LDS in front of it must not shift it by 8)
     double *lds_dw = lds_dyn;
     double2 *tile = reinterpret_cast<double2 *>(lds_dyn + (TAB ? (TAB_LDS(pc.nq)) : 0));      // !TAB: dW knots recomputed (density_wt)
     __shared__ double s_sink[4][MAX_SINKS];              // x, y, z, m of the sinks: the epilogue reads them here, not through serial scalar loads
@@ -429,11 +441,16 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
     // groups of that eighth in turn
     const int nx = min(8, (int)gridDim.x), xcd = blockIdx.x % nx, per = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int64_t g_hi = (int64_t)ngroups * (xcd + 1) / nx;
-    const double inv_h = 1.0 / pc.h, inv_dq = 0.5 * pc.nq;
+    const double inv_h = pc.inv_h, inv_dq = pc.inv_dq;
     auto dw_of = [&](double q) {
         const double t = knot_coord(q, inv_dq);
         return TAB ? table_knots_at(lds_dw, t) : knot_knots_at([&](int k) { return dw_knot(k, pc.dq, pc.nq); }, t);
     };
+    // What only the epilogue needs of the kernel's arguments waits in LDS: 22 scalar registers less across the pair loop, which
+    // has none to spare (the three fall-back variants of this kernel spilled 10-19 of them before)
+    __shared__ EpiArgs s_epi;
+    if (threadIdx.x == 0)
+        s_epi = EpiArgs{pc.G, pc.alpha_floor, pc.alpha_decay, pc.inv_dwnorm, ax, ay, az, du, dalpha, pc.ns, pc.grav};
     if (threadIdx.x < 4 * MAX_SINKS) {
         const int row = threadIdx.x / MAX_SINKS, s = threadIdx.x % MAX_SINKS;
         s_sink[row][s] = s < pc.ns ? sink[(row == 3 ? 6 : row) * MAX_SINKS + s] : 0.0;
@@ -576,10 +593,13 @@ __global__ __launch_bounds__(BS) void forces_q(PairConst pc, int32_t tcap, int32
         // a target take one channel each (three acceleration components, du/dt) and store it; what the channels share (the
         // distance to each sink) is computed by all of them at the cost of one.
         if (live && sub < 4) {
-            double *const out = sub == 0 ? ax : (sub == 1 ? ay : (sub == 2 ? az : du));
-            const double start = (pc.grav && sub < 3) ? out[i] : 0.0;
-            out[i] = force_channel(pc, sk, A, f, start, sub);
-            if (sub == 3) dalpha[i] = alpha_rate(pc, inv_h, B.w, Cc.x, Cc.y, f);
+            const EpiArgs ea = s_epi;
+            PairConst pe;
+            pe.G = ea.G; pe.alpha_floor = ea.alpha_floor; pe.alpha_decay = ea.alpha_decay; pe.inv_dwnorm = ea.inv_dwnorm; pe.ns = ea.ns;
+            double *const out = sub == 0 ? ea.ax : (sub == 1 ? ea.ay : (sub == 2 ? ea.az : ea.du));
+            const double start = (ea.grav && sub < 3) ? out[i] : 0.0;
+            out[i] = force_channel(pe, sk, A, f, start, sub);
+            if (sub == 3) ea.dalpha[i] = alpha_rate(pe, inv_h, B.w, Cc.x, Cc.y, f);
         }
 #ifdef SPH_PHASE_CLOCKS
         pa_n++;
