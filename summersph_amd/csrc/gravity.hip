@@ -266,21 +266,20 @@ __global__ __launch_bounds__(GB) void grav_walk(int n, TreeArrays t, RootBox rb,
             next_open = wb.x; next_skip = wb.y;
         }
         const double d0 = p.x - c.x, d1 = p.y - c.y, d2c = p.z - c.z;  // [F]:274
-        const double d2 = (d0 * d0 + d1 * d1 + d2c * d2c) + soft2;    // [F]:275
+        const double d2 = fma(d2c, d2c, fma(d1, d1, fma(d0, d0, soft2)));    // [F]:275
         // [F]:278: size/dist < theta  <=>  size^2 < theta^2 d2 (all positive): opened nodes need neither the
         // square root nor the division (the two forms can only disagree within an ulp of the threshold)
         if (leaf || size * size < theta2 * d2) {
             if (c.w > 0.0) {
                 const double rs = fast_rsqrt(d2);
+                double f = (G * c.w) * ((rs * rs) * rs);              // [F]:281: G M [W] / dist^3
                 const double qi = (d2 * rs) * inv_hp;                  // dist / h
-                double W = 1.0;                                        // [F]:129-146: 1 beyond the softening support
-                if (qi <= 2.0) {
+                if (qi <= 2.0) {                                       // [F]:129-146: W = 1 beyond the softening support
                     const double tq = qi * inv_dq;
                     const int k = min((int)tq, nq - 1);
                     const double a = tq - (double)k;
-                    W = (1.0 - a) * gt[k] + a * gt[k + 1];
+                    f *= (1.0 - a) * gt[k] + a * gt[k + 1];
                 }
-                const double f = (G * c.w) * W * (rs * rs * rs);      // [F]:281: G M W / dist^3
                 a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
             }
             node = next_skip;
@@ -292,33 +291,33 @@ __global__ __launch_bounds__(GB) void grav_walk(int n, TreeArrays t, RootBox rb,
 }
 
 // One 64-byte record per node for the wave walk, leaves behind the internal nodes (unified index: internal i -> i,
-// leaf j -> n - 1 + j): centre of mass + mass, the squared edge of the node's smallest box (-1 for a leaf: always
+// leaf j -> n - 1 + j): centre of mass + G x mass, the squared edge of the node's smallest box (-1 for a leaf: always
 // accepted), both successors, and for leaves the cell-sorted slot (to recognise the target's own leaf).
 struct alignas(64) WalkRec {
-    double cx, cy, cz, m;
+    double cx, cy, cz, gm;              // centre of mass, G m (first 32 bytes: what the contribution needs, one scalar load)
     double size2;
     int32_t next_open, next_skip;       // unified indices, END terminates
-    int32_t slot, pad0;
-    double pad1;
+    int32_t slot, has_mass;             // has_mass: m > 0 (a wave-uniform test in the walk, not a vector compare)
+    double pad;
 };
 
 __device__ __forceinline__ int unified(int node, int n) { return node == END ? END : (node < 0 ? n - 1 + ~node : node); }
 
-__global__ __launch_bounds__(GB) void node_wave_records(int n, TreeArrays t, RootBox rb, double theta2, WalkRec *__restrict__ rec,
+__global__ __launch_bounds__(GB) void node_wave_records(int n, TreeArrays t, RootBox rb, double theta2, double G, WalkRec *__restrict__ rec,
                                                         int32_t *__restrict__ leaf_of) {
     const int i = blockIdx.x * GB + threadIdx.x;
     if (i < n - 1) {
         const int4 wb = t.walkB[i];
         const double4 c = t.sum[i];
         const double size = ldexp(rb.size, -wb.z);
-        WalkRec r{c.x, c.y, c.z, c.w, (size * size) / theta2, unified(wb.x, n), unified(wb.y, n), -1, 0, 0.0};   // theta = 0.5: exact
+        WalkRec r{c.x, c.y, c.z, G * c.w, (size * size) / theta2, unified(wb.x, n), unified(wb.y, n), -1, c.w > 0.0 ? 1 : 0, 0.0};   // theta = 0.5: exact
         rec[i] = r;
     }
     if (i < n) {
         const int2 lb = t.leafB[i];
         const double4 c = t.leafA[i];
         const int nx = unified(lb.x, n);
-        WalkRec r{c.x, c.y, c.z, c.w, -1.0, nx, nx, lb.y, 0, 0.0};
+        WalkRec r{c.x, c.y, c.z, G * c.w, -1.0, nx, nx, lb.y, c.w > 0.0 ? 1 : 0, 0.0};
         rec[n - 1 + i] = r;
         leaf_of[lb.y] = i;                   // cell-sorted slot -> leaf (key order)
     }
@@ -357,30 +356,40 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
     unsigned visits = 0, sums = 0;
     // (Requesting both successors' records before the acceptance tests run -- so that the scalar-load latency overlaps the
     // tests -- changes nothing: 4.06 ms per step either way; the walk is bound by vector issue, not by the pointer chase.)
+    // Per visit the walk issues ~23 vector instructions where round 2's issued 33: which lanes are awake is a 64-bit mask in scalar
+    // registers (compares deliver masks, __builtin_amdgcn_fcmp / icmp; a mask predicates vector code for free, inverse_ballot), G m
+    // and "has mass" come with the record, W multiplies only inside the softening support, and the softening length enters the
+    // squared distance through the first fma.
+    constexpr int CMP_EQ = 32, CMP_NE = 33, CMP_OLT = 4;                  // llvm::CmpInst predicates of the two builtins
+    unsigned long long act_m = __builtin_amdgcn_ballot_w64(active);       // lanes walking; the others sleep until their rope (resume)
     while (node != END) {
         node = __builtin_amdgcn_readfirstlane(node);
-        if (!active && resume == node) active = true;
         const WalkRec r = rec[node];
+        act_m |= __builtin_amdgcn_uicmp((unsigned)resume, (unsigned)node, CMP_EQ);      // a sleeper wakes at the rope of the node it accepted
         const int n_open = r.next_open, n_skip = r.next_skip;
         const double d0 = p.x - r.cx, d1 = p.y - r.cy, d2c = p.z - r.cz;  // [F]:274
-        const double d2 = (d0 * d0 + d1 * d1 + d2c * d2c) + soft2;        // [F]:275
-        const bool accept = r.size2 < d2;                                 // [F]:278, see grav_walk: size2 holds edge^2 / theta^2 (leaves: -1)
-        const bool open_any = __any(active && !accept);
-        if (active && accept && node != own && r.m > 0.0) {               // own leaf: direction = 0, contributes nothing
-            const double rs = fast_rsqrt(d2);
-            double W = 1.0;                                                // [F]:129-146: 1 beyond the softening support
-            if (d2 <= rsoft2) {
-                const double qi = (d2 * rs) * inv_hp;                      // dist / h
-                if (qi <= 2.0) {
-                    const double tq = qi * inv_dq;
-                    const int k = min((int)tq, nq - 1);
-                    const double a = tq - (double)k;
-                    W = (1.0 - a) * gt[k] + a * gt[k + 1];
+        const double d2 = fma(d2c, d2c, fma(d1, d1, fma(d0, d0, soft2)));  // [F]:275
+        // [F]:278, see grav_walk: size2 holds edge^2 / theta^2 (leaves: -1, always accepted)
+        const unsigned long long acc_m = __builtin_amdgcn_fcmp(r.size2, d2, CMP_OLT);
+        const unsigned long long done_m = act_m & acc_m;                  // awake and satisfied with this node
+        const bool open_any = (act_m & ~acc_m) != 0;                      // some awake lane has to open it
+        if (r.has_mass) {
+            // own leaf: direction = 0, contributes nothing
+            if (__builtin_amdgcn_inverse_ballot_w64(done_m & __builtin_amdgcn_uicmp((unsigned)own, (unsigned)node, CMP_NE))) {
+                const double rs = fast_rsqrt(d2);
+                double f = r.gm * ((rs * rs) * rs);                       // [F]:281: G M [W] / dist^3
+                if (d2 <= rsoft2) {
+                    const double qi = (d2 * rs) * inv_hp;                  // dist / h
+                    if (qi <= 2.0) {                                       // [F]:129-146: W = 1 beyond the softening support
+                        const double tq = qi * inv_dq;
+                        const int k = min((int)tq, nq - 1);
+                        const double a = tq - (double)k;
+                        f *= (1.0 - a) * gt[k] + a * gt[k + 1];
+                    }
                 }
+                a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
+                if (STATS) sums++;
             }
-            const double f = (G * r.m) * W * (rs * rs * rs);              // [F]:281
-            a0 = fma(-f, d0, a0); a1 = fma(-f, d1, a1); a2 = fma(-f, d2c, a2);
-            if (STATS) sums++;
         }
         if (STATS) visits++;
         if (STATS && (threadIdx.x & 63) == 0) {          // debug histogram: visits by node size (levels below the root)
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(GB) void grav_walk_wave(int nt, int n, const WalkRe
             atomicAdd(&stats[2 + (r.size2 > 0.0 ? lv : 15)], 1ull);
         }
         if (open_any) {
-            if (active && accept) { active = false; resume = n_skip; }       // done with this subtree
+            resume = __builtin_amdgcn_inverse_ballot_w64(done_m) ? n_skip : resume;      // done with this subtree: sleep until its rope
+            act_m &= ~done_m;
             node = n_open;
         } else {
             node = n_skip;
@@ -538,7 +548,7 @@ int gravity_tree_build(sph_ctx *c) {
     }
     node_finish<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
     node_walk_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t);
-    node_wave_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t, rb, c->p.theta * c->p.theta, reinterpret_cast<WalkRec *>(c->g_wrec), c->g_leaf_of);
+    node_wave_records<<<dim3(gb), dim3(GB), 0, c->stream>>>((int)n, t, rb, c->p.theta * c->p.theta, c->p.G, reinterpret_cast<WalkRec *>(c->g_wrec), c->g_leaf_of);
     GR_CHECK2(hipGetLastError());
     return SPH_OK;
 }
