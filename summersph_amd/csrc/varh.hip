@@ -555,7 +555,7 @@ __device__ __forceinline__ void density_visit_v(const double4 &pi, const double4
                                                 const double *__restrict__ ldw, double inv_h, double inv_dq, int nq, DensSumsV &d) {
     const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;              // [V]:481
     double dr, rs;
-    fast_sqrt_rsqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                            // [V]:482
+    rsqrt_sqrt(n0 * n0 + n1 * n1 + n2 * n2, dr, rs);                                 // [V]:482
     const double qi = dr * inv_h;
     if (act && qi <= 2.0) {
         double wl, dwl;
@@ -590,7 +590,7 @@ __device__ __forceinline__ void force_visit_v(const PairConst &pc, double hi, do
     const double n0 = A.x - Aj.x, n1 = A.y - Aj.y, n2 = A.z - Aj.z;                   // [V]:385
     const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
     double dr, rs;
-    fast_sqrt_rsqrt(r2, dr, rs);
+    rsqrt_sqrt(r2, dr, rs);
     if (act && r2 > 0.0) {
         const double hj = Cj.w;
         const double inv_hj = fast_rcp(hj);
@@ -605,9 +605,11 @@ __device__ __forceinline__ void force_visit_v(const PairConst &pc, double hi, do
         const double dWs = 0.5 * (dWo + dWn);
         const double vdotgradW = (vr * rs) * dWs;                                     // [V]:401
         const double avg_len = 0.5 * (hi + hj);                                       // [V]:402
-        const double vis_nu = (avg_len * vdotr) * fast_rcp(r2 + pc.visc_eps_h2 * avg_len * avg_len);   // [V]:405
+        double inv_r2e, inv_rho;                                                      // one reciprocal for the two denominators
+        rcp_pair(r2 + pc.visc_eps_h2 * avg_len * avg_len, B.w + Bj.w, inv_r2e, inv_rho);
+        const double vis_nu = (avg_len * vdotr) * inv_r2e;                            // [V]:405
         const double cbar = Cc.x + Cj.x, abar = Cc.y + Cj.y;
-        const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * fast_rcp(B.w + Bj.w);           // [V]:410
+        const double visc = (abar * vis_nu) * (2.0 * vis_nu - cbar) * inv_rho;        // [V]:410
         const double S = (Cc.z * dWo + Cj.z * dWn + visc * dWs) * rs;                 // [V]:413-414 (along n)
         const double mS = Aj.w * S;
         f.s0 = fma(mS, n0, f.s0); f.s1 = fma(mS, n1, f.s1); f.s2 = fma(mS, n2, f.s2); // [V]:416
@@ -913,6 +915,31 @@ __global__ __launch_bounds__(VBLOCK) void forces_v_kernel(PairConst pc, const do
 
 
 // ---- calc_smoothing -------------------------------------------------------------------------------------
+// One partner of a trial length hn: the two sums of density_visit_v (sum m w(q), sum m (q dw(q) - 3 w(q))), normalised once per
+// trial in h_trial_finish -- [V]:482-493 divides every pair by pi hn^3, pi hn^4 and hn (with the square root and the three
+// divisions of the table lookup: seven IEEE operations of ~30 instructions each per partner; round 3 measured calc_smoothing
+// at 0.54 ms per step with them).  Beyond 2 hn both knots are the tables' final zeros: no test of q.
+__device__ __forceinline__ void h_trial_visit(const double4 &pi, const double4 &pj, double inv_hn, double inv_dq,
+                                              const double *__restrict__ w_tab, const double *__restrict__ dw_tab, DensSumsV &d) {
+#pragma clang fp contract(off)
+    const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
+    double dr, rs;
+    rsqrt_sqrt(fma(n2, n2, fma(n1, n1, n0 * n0)), dr, rs);
+    const double qi = dr * inv_hn;
+    const double t = knot_coord(qi, inv_dq);
+    const int k = (int)t;
+    const double a = __builtin_amdgcn_fract(t), b = 1.0 - a;
+    const double wl = fma(a, w_tab[k + 1], b * w_tab[k]), dwl = fma(a, dw_tab[k + 1], b * dw_tab[k]);
+    d.s1 = fma(pj.w, wl, d.s1);
+    d.s2 = fma(pj.w, fma(qi, dwl, -3.0 * wl), d.s2);
+}
+__device__ __forceinline__ void h_trial_finish(const PairConst &pc, double hn, const DensSumsV &d, double &rho, double &om) {
+    const double h3 = hn * hn * hn;
+    rho = d.s1 / (pc.kernel_pi * h3);                                                       // [V]:139
+    const double om_acc = -d.s2 / (pc.kernel_pi * ((hn * hn) * (hn * hn)));                 // [V]:140,487
+    om = 1.0 + (hn / (3.0 * rho)) * om_acc;                                                 // [V]:535
+}
+
 // rho and Omega of ONE body with trial length hn on the tree of the last evaluation (leaf boxes and
 // reaches hold the OLD h of every particle), [V]:531-535 -> density_tree_search
 __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec, const double4 *__restrict__ lrec,
@@ -923,8 +950,8 @@ __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec,
     cell_coords(g, pi.x, pi.y, pi.z, cc);
     const int R = max((int)ceil(2.0 * hn * g.inv_edge), 1);
     const int d0 = g.dim[g.s[0]], d1 = g.dim[g.s[1]], d2 = g.dim[g.s[2]];
-    double r0 = 0.0, oa = 0.0;
-    const double n3 = pc.kernel_pi * (hn * hn * hn), n4 = pc.kernel_pi * ((hn * hn) * (hn * hn));
+    DensSumsV d;
+    const double inv_hn = 1.0 / hn, inv_dq = 0.5 * pc.nq, rt2 = 4.0 * hn * hn * (1.0 + 1e-12);
     for (int c2 = max(cc[2] - R, 0); c2 <= min(cc[2] + R, d2 - 1); c2++)
         for (int c1 = max(cc[1] - R, 0); c1 <= min(cc[1] + R, d1 - 1); c1++) {
             const int64_t row = ((int64_t)c2 * d1 + c1) * d0;
@@ -932,24 +959,13 @@ __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec,
             for (int j = jb; j < je; j++) {
                 const double4 pj = drec[j];
                 const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
-                const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-                if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) continue;       // cheap pre-test; the exact one follows
+                if (n0 * n0 + n1 * n1 + n2 * n2 > rt2) continue;        // cheap pre-test (beyond 2 hn the visit adds zeros anyway)
                 const double4 lj = lrec[j];
                 if (!reaches(lj, pi.x, pi.y, pi.z)) continue;
-                const double dr = sqrt(r2);
-                const double qi = dr / hn;
-                if (qi > 2.0) continue;
-                int k = min((int)(qi / pc.dq), pc.nq - 1);
-                const double a = (qi - k * pc.dq) / pc.dq;
-                const double Wj = ((1.0 - a) * w_tab[k] + a * w_tab[k + 1]) / n3;
-                const double dWj = ((1.0 - a) * dw_tab[k] + a * dw_tab[k + 1]) / n4;
-                const double W_h = -(dr * dWj - 3.0 * Wj) / hn;                           // [V]:487
-                r0 = r0 + pj.w * Wj;
-                oa = oa + pj.w * W_h;
+                h_trial_visit(pi, pj, inv_hn, inv_dq, w_tab, dw_tab, d);
             }
         }
-    rho = r0;
-    om = 1.0 + (hn / (3.0 * r0)) * oa;                                                     // [V]:535
+    h_trial_finish(pc, hn, d, rho, om);
 }
 
 // the same sums from the body's neighbour list: valid while the trial length stays inside the margin shell the list
@@ -957,30 +973,13 @@ __device__ void density_one(const GridDesc &g, const double4 *__restrict__ drec,
 __device__ void density_list(const double4 *__restrict__ drec, const int4 *__restrict__ mine, int cap4, int cnt, int tcnt,
                              const double *__restrict__ w_tab, const double *__restrict__ dw_tab, const PairConst &pc,
                              const double4 &pi, double hn, double &rho, double &om) {
-    const double n3 = pc.kernel_pi * (hn * hn * hn), n4 = pc.kernel_pi * ((hn * hn) * (hn * hn));
-    double r0 = 0.0, oa = 0.0;
-    {   // the body itself (r = 0; its own leaf is always reached)
-        const double Wj = w_tab[0] / n3, dWj = dw_tab[0] / n4;
-        const double W_h = -(0.0 * dWj - 3.0 * Wj) / hn;
-        r0 = r0 + pi.w * Wj;
-        oa = oa + pi.w * W_h;
-    }
+    DensSumsV d;
+    const double inv_hn = 1.0 / hn, inv_dq = 0.5 * pc.nq;
+    d.s1 = pi.w * w_tab[0];                            // the body itself (r = 0; its own leaf is always reached)
+    d.s2 = pi.w * (-3.0 * w_tab[0]);
     auto visit = [&](uint32_t ent) {
         if (!(ent & FLAG_R)) return;
-        const double4 pj = drec[ent & IDX_MASK];
-        const double n0 = pi.x - pj.x, n1 = pi.y - pj.y, n2 = pi.z - pj.z;
-        const double r2 = n0 * n0 + n1 * n1 + n2 * n2;
-        if (r2 > 4.0 * hn * hn * (1.0 + 1e-12)) return;
-        const double dr = sqrt(r2);
-        const double qi = dr / hn;
-        if (qi > 2.0) return;
-        int kq = min((int)(qi / pc.dq), pc.nq - 1);
-        const double a = (qi - kq * pc.dq) / pc.dq;
-        const double Wj = ((1.0 - a) * w_tab[kq] + a * w_tab[kq + 1]) / n3;
-        const double dWj = ((1.0 - a) * dw_tab[kq] + a * dw_tab[kq + 1]) / n4;
-        const double W_h = -(dr * dWj - 3.0 * Wj) / hn;                               // [V]:487
-        r0 = r0 + pj.w * Wj;
-        oa = oa + pj.w * W_h;
+        h_trial_visit(pi, drec[ent & IDX_MASK], inv_hn, inv_dq, w_tab, dw_tab, d);
     };
     // one 16-byte row = four entries; the D/F entries from the top of the column, the margin shell from its bottom
     for (int row = 0; 4 * row < cnt; row++) {
@@ -999,8 +998,7 @@ __device__ void density_list(const double4 *__restrict__ drec, const int4 *__res
         if (left > 2) visit((uint32_t)q.z);
         if (left > 3) visit((uint32_t)q.w);
     }
-    rho = r0;
-    om = 1.0 + (hn / (3.0 * r0)) * oa;                                                 // [V]:535
+    h_trial_finish(pc, hn, d, rho, om);
 }
 
 __global__ __launch_bounds__(VBLOCK) void update_h_kernel(GridDesc g, PairConst pc, const double4 *__restrict__ drec,
