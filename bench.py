@@ -87,6 +87,12 @@ def load_limiters():
     return d, os.path.relpath(cand[-1], ROOT), (sha != csrc_sha256())
 
 
+# Inside a timed region the dominant kernel group is bracketed by HIP events -- every EVENT_STRIDE-th launch of it: an event pair
+# costs the stream ~14 us (measured: 1.19 ms per step with every force launch bracketed, 1.13-1.14 without any), and the
+# roofline's duration is a mean over launches anyway.  Odd, so that with N > 1 (interior and boundary launches alternate) both kinds
+# are sampled.
+EVENT_STRIDE = int(os.environ.get("SPH_BENCH_EVENT_STRIDE", "5"))
+
 def roofline_record(lim, workload, prefixes, alg_bytes, avg_launch_s, launches, lane_eff, n, default_n=1_000_000):
     """roofline object of one kernel: algorithmic bytes / measured duration against the HBM peak, plus what the committed
     counter passes say limits it (only when they were taken on this workload size)"""
@@ -113,7 +119,8 @@ def roofline_record(lim, workload, prefixes, alg_bytes, avg_launch_s, launches, 
         limiter["avg_launch_us_rocprof"] = rec.get("avg_us")
     return {"bound": bound, "kernel": name or prefixes[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": rec.get("traffic_bytes_per_launch") if rec else None,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "limiter": limiter}
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+            "launches_bracketed": f"every {EVENT_STRIDE}th launch of the timed region carries the HIP-event pair", "limiter": limiter}
 
 
 def usable_cores():
@@ -256,7 +263,7 @@ def stats_dict(st):
             "device_bytes": st.device_bytes, "slots": int(st.n)}
 
 
-def timed_run(wl, steps, warmup, dominant=("forces",), breakdown=True, repeats=0, late_window=None):
+def timed_run(wl, steps, warmup, dominant=("forces",), breakdown=True, repeats=0, late_window=None, preheat=True):
     """-> dict(elapsed, dt, table, stats, repeat_ms, late).  Inside the timed region only the `dominant` kernel groups are
     bracketed by HIP events (the roofline's duration is measured live there; bracketing every group costs ~4 % of a
     fixed-h step).  `stats` is read directly after the timed region: it describes the state the timed steps ran on.
@@ -269,7 +276,7 @@ def timed_run(wl, steps, warmup, dominant=("forces",), breakdown=True, repeats=0
     def one(keep_timing):
         dt, t = ctx.run(warmup, 1e-2, 0.0)
         if keep_timing:
-            ctx.timing(True, only=list(dominant)); ctx.timing_reset()
+            ctx.timing(True, only=list(dominant), stride=EVENT_STRIDE); ctx.timing_reset()
         ctx.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         dt, t = ctx.run(steps, dt, t)
@@ -279,8 +286,16 @@ def timed_run(wl, steps, warmup, dominant=("forces",), breakdown=True, repeats=0
             ctx.timing(False)
         return el, dt, t
 
+    if preheat:
+        # One untimed pass of the same W + K steps first, then the same upload again: the timed region of the default run is
+        # ~25 ms long and, started on an idle GPU, fell into the clock ramp (measured: 1.166 ms per step against 1.13 for
+        # every later pass of the same trajectory; with 30 warm-up steps the first pass gives 1.119 like the later ones).
+        one(False)
+        wl.reset()
     el, dt, t = one(True)
     table = {k: ctx.timing_get(k) for k in capi.KERNELS}
+    for k in dominant:                                  # every EVENT_STRIDE-th launch was bracketed: the group's total, extrapolated
+        table[k] = (table[k][0] * EVENT_STRIDE, table[k][1] * EVENT_STRIDE)
     st = ctx.stats()                                   # the state of the timed steps, nothing ran since
     out = {"elapsed": el, "dt": dt, "stats": st, "n_left": ctx.n, "repeat_ms": None, "late": None}
     if breakdown:
@@ -420,9 +435,16 @@ def dist_run(env, rows, variable, flags, steps, warmup, halo_mode, dominant=("fo
     def barrier():
         ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
 
+    # clocks at their working level before the (short) timed region: ~100 ms of unrelated work on the same device
+    heat = torch.ones(2048, 2048, device=f"cuda:{env['local_rank']}" if "local_rank" in env else "cuda")
+    t_h = time.perf_counter()
+    while time.perf_counter() - t_h < 0.1:
+        heat = (heat @ heat) * (1.0 / 2048.0)
+        torch.cuda.synchronize()
+    del heat
     dt = sim.run(warmup, 1e-2)
     sim.profile = profile
-    ctx.timing(True, only=list(dominant)); ctx.timing_reset()        # the other groups: untimed inside the region
+    ctx.timing(True, only=list(dominant), stride=EVENT_STRIDE); ctx.timing_reset()        # the other groups: untimed inside the region
     barrier()
     t0 = time.perf_counter()
     dt = sim.run(steps, dt)
@@ -440,6 +462,8 @@ def dist_run(env, rows, variable, flags, steps, warmup, halo_mode, dominant=("fo
     if rank == 0:
         out["stats"] = ctx.stats()
         out["table"] = {k: ctx.timing_get(k) for k in capi.KERNELS}
+        for k in dominant:                              # every EVENT_STRIDE-th launch was bracketed (see EVENT_STRIDE)
+            out["table"][k] = (out["table"][k][0] * EVENT_STRIDE, out["table"][k][1] * EVENT_STRIDE)
         if profile:
             out["phase_ms_per_step"] = {k: 1e3 * v / steps for k, v in sim.phase_s.items()}
     if hasattr(sim, "close"):
@@ -604,6 +628,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             # restarts of the same state (same upload, same warm-up, the same K steps): run-to-run spread
             "repeat_ms_per_step": res["repeat_ms"] if world == 1 else None,
+            "preheat": ("one untimed pass of the same W + K steps, then the same upload again, before the W warm-up + K timed steps"
+                        if world == 1 else "~100 ms of unrelated device work before the W warm-up steps")
+                       + " (the timed region is ~25 ms: started on an idle GPU it falls into the clock ramp)",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name, "mode": args.mode, "n_particles_per_gpu": args.n, "mean_neighbours": st.nlist_mean, "mean_wave_trips": st.nlist_wave_mean,
                        "stats_read": "directly after the timed region",

@@ -358,6 +358,10 @@ int sph_get_bbox(sph_ctx *ctx, double *lo, double *hi);
 /* HIP events around kernel groups: on = 0 none, 1 every group, else a mask with bit (k + 1) set for sph_kernel_id k (timing
  * one group costs two event records per launch of that group; timing all of them ~4 % of a fixed-h step)                */
 int sph_timing_enable(sph_ctx *ctx, int on);
+/* bracket only every stride-th launch of a timed group (default 1): an event pair costs the stream ~14 us, so a run that is
+ * itself being timed samples its dominant kernel instead of bracketing every launch; sph_timing_get then returns the
+ * bracketed launches and their total                                                                                      */
+int sph_timing_stride(sph_ctx *ctx, int stride);
 int sph_timing_reset(sph_ctx *ctx);
 int sph_timing_get(sph_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int sph_synchronize(sph_ctx *ctx);

@@ -40,7 +40,7 @@ SYMBOLS = [
     "sph_set_stream", "sph_reserve", "sph_owned_bbox", "sph_select_boxes", "sph_selected_ids_dev", "sph_select_boxes_async", "sph_selected_counts", "sph_gather_selected_dev", "sph_replace_ghosts_dev",
     "sph_set_dt", "sph_get_dt", "sph_kick_devdt", "sph_drift_devdt", "sph_dt_candidate_dev", "sph_kick_drift_devdt", "sph_kick_dt_candidate_dev", "sph_kick_dt_candidate_gas_dev", "sph_kick_sinks_devdt", "sph_pack_partials_dev", "sph_pack_partials_ex_dev",
     "sph_apply_partials_dev", "sph_set_boundary_boxes", "sph_forces_part", "sph_set_gravity_sources_dev", "sph_accrete_mark_dev", "sph_accrete_apply_dev", "sph_set_numbers_dev",
-    "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
+    "sph_get_stats", "sph_get_bbox", "sph_timing_enable", "sph_timing_stride", "sph_timing_reset", "sph_timing_get", "sph_synchronize", "sph_stream",
 ]
 
 
@@ -155,6 +155,7 @@ def load():
     lib.sph_set_numbers_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.sph_accrete_apply_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.sph_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.sph_timing_stride.argtypes = [C.c_void_p, C.c_int]
     lib.sph_timing_get.argtypes = [C.c_void_p, C.c_int, _D, C.POINTER(C.c_int64)]
     _lib = lib
     return lib
@@ -456,9 +457,11 @@ class Context:
         self._ck(self.lib.sph_get_bbox(self._h, lo, hi))
         return np.array(lo[:]), np.array(hi[:])
 
-    def timing(self, on, only=None):
-        """HIP events around every kernel group (on=True), none (False), or only the groups named in `only`"""
+    def timing(self, on, only=None, stride=1):
+        """HIP events around every kernel group (on=True), none (False), or only the groups named in `only`; stride: bracket
+        only every stride-th launch of a timed group (a sample: timing_get returns the bracketed launches)"""
         mask = 0 if not on else (1 if only is None else sum(2 << KERNELS.index(k) for k in only))
+        self._ck(self.lib.sph_timing_stride(self._h, max(int(stride), 1)))
         self._ck(self.lib.sph_timing_enable(self._h, mask))
 
     def timing_reset(self):

@@ -145,7 +145,7 @@ void host_grav_table(int nq, std::vector<double> &g) {
 struct Timed {
     sph_ctx *c; int id; hipEvent_t e0 = nullptr, e1 = nullptr;
     Timed(sph_ctx *c_, int id_) : c(c_), id(id_) {
-        if (c->timing & (1u << id)) {
+        if ((c->timing & (1u << id)) && (c->timing_seen[id]++ % c->timing_stride) == 0) {
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, c->stream);
         }
@@ -1161,6 +1161,13 @@ int sph_get_bbox(sph_ctx *c, double *lo, double *hi) {
 int sph_timing_enable(sph_ctx *c, int on) {
     if (!c || on < 0) return SPH_ERR_ARG;
     c->timing = on == 1 ? 0xffffffffu : ((unsigned)on >> 1);       // 1: every group; else bit k + 1 = group k
+    for (auto &s : c->timing_seen) s = 0;
+    return SPH_OK;
+}
+
+int sph_timing_stride(sph_ctx *c, int stride) {
+    if (!c || stride < 1) return SPH_ERR_ARG;
+    c->timing_stride = stride;
     return SPH_OK;
 }
 

@@ -206,6 +206,8 @@ struct sph_ctx {
     std::unordered_map<void *, size_t> allocs;   // every device allocation of this context
     int32_t rank = 0, nranks = 1;   // multi-GPU: only rank 0 adds the sink-sink pair terms before the all-reduce
     unsigned timing = 0;             // bit k: kernel group k is bracketed by HIP events
+    int timing_stride = 1;           // ... every timing_stride-th launch of it (sph_timing_stride)
+    int64_t timing_seen[32] = {};    // launches of group k since timing was switched on
     sph::TimingSlot tslot[SPH_K_COUNT];
 };
 
