@@ -431,3 +431,26 @@ def test_positions_overwritten_in_steady_state_do_not_run_on_truncated_lists(cap
     for f in ("rho", "ax", "ay", "az", "du", "dalpha"):
         assert rel_err(ctx.field(f), getattr(o, f)) <= EVAL_TOL, f
     ctx.close()
+
+
+def test_event_timing_samples_every_nth_launch(capi):
+    """sph_timing_stride: only every stride-th launch of a timed group carries the HIP-event pair (bench.py samples its
+    dominant kernel that way); the other groups stay untimed, and the results do not depend on it."""
+    gas, sinks = ic.split_rows(ic.keplerian_disc(20000, seed=5, nngb=60.0))
+    ctx = capi.Context(device=0)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    ctx.density(); ctx.forces()
+    ref = ctx.field("ax").copy()
+    ctx.timing(True, only=["forces"], stride=3); ctx.timing_reset()
+    for _ in range(6):
+        ctx.density(); ctx.forces()
+    ctx.synchronize()
+    ms, launches = ctx.timing_get("forces")
+    assert launches == 2 and ms > 0.0
+    assert ctx.timing_get("density")[1] == 0
+    ctx.timing(True, only=["forces"]); ctx.timing_reset()          # stride back to 1
+    ctx.density(); ctx.forces(); ctx.synchronize()
+    assert ctx.timing_get("forces")[1] == 1
+    ctx.timing(False)
+    assert np.array_equal(ctx.field("ax"), ref)
+    ctx.close()
