@@ -454,3 +454,42 @@ def test_event_timing_samples_every_nth_launch(capi):
     ctx.timing(False)
     assert np.array_equal(ctx.field("ax"), ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("flags_name", ["tile", "gather"])
+def test_pairs_on_the_edge_of_the_support_and_coincident_points(capi, flags_name):
+    """The pair visits carry no test of q and no mask for r = 0 (round 3): beyond 2h both table knots are the final zeros, dw(0) = 0.
+    Planted pairs at exactly r = 2h, one ulp inside and outside, at r = 2h(1 +- 1e-9), and two coincident particles, in a disc
+    patch dense enough for the tile kernels -- against the CPU oracle, which tests q <= 2 as the reference does (and, like it, divides by
+    r = 0 for the coincident pair: those two particles' rates are NaN there and finite here)."""
+    from oracle import orc
+    gas, sinks = ic.split_rows(ic.keplerian_disc(30000, seed=77, nngb=70.0))
+    rng = np.random.default_rng(8)
+    gas["vx"] = gas["vx"] + rng.normal(0.0, 0.05, gas["x"].size)
+    gas["alpha"] = np.full(gas["x"].size, 0.4)
+    h = 2.5
+    base = np.argsort(np.hypot(gas["x"] - 40.0, gas["y"]))[:12]           # twelve particles in the bulk take planted partners
+    d = [2.0 * h, np.nextafter(2.0 * h, 0.0), np.nextafter(2.0 * h, 10.0), 2.0 * h * (1 - 1e-9), 2.0 * h * (1 + 1e-9), 0.0]
+    for k, dist in enumerate(d):
+        a, b = base[2 * k], base[2 * k + 1]
+        gas["x"][b] = gas["x"][a] + dist
+        gas["y"][b] = gas["y"][a]
+        gas["z"][b] = gas["z"][a]
+    flags = 0 if flags_name == "tile" else capi.FLAG_NO_WHOLE_TILE
+    ctx = capi.Context(device=0, flags=flags)
+    ctx.upload(gas); ctx.set_sinks(sinks)
+    ctx.density(); ctx.forces()
+    st = ctx.stats()
+    if flags_name == "tile":
+        assert st.tile_fit_pct_forces >= 90
+    o = orc.Oracle(gas, sinks)
+    o.evaluate()
+    twins = base[10:12]                     # the coincident pair: the reference divides by r = 0 there (NaN), the kernels add zeros
+    others = np.ones(gas["x"].size, bool); others[twins] = False
+    assert rel_err(ctx.field("rho"), o.rho) <= EVAL_TOL                     # a coincident partner counts with W(0) in the density
+    for f in ("ax", "ay", "az", "du", "dalpha"):
+        got, want = ctx.field(f), getattr(o, f)
+        assert np.all(np.isfinite(got)), f
+        assert np.all(np.isfinite(want[others])), f
+        assert rel_err(got[others], want[others]) <= EVAL_TOL, f
+    ctx.close()
