@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "sph_internal.hpp"
+#include "integ_common.hpp"
 
 namespace sph {
 
@@ -27,11 +28,11 @@ __global__ __launch_bounds__(EW_BLOCK) void kick_kernel(KickArgs a, int64_t n, d
     const double dt = dt_ptr ? dt_ptr[0] : dt_val;
     const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     if (i < n) {
-        a.vx[i] = a.vx[i] + 0.5 * a.ax[i] * dt;               // [F]:749-751
-        a.vy[i] = a.vy[i] + 0.5 * a.ay[i] * dt;
-        a.vz[i] = a.vz[i] + 0.5 * a.az[i] * dt;
-        a.u[i] = a.u[i] + 0.5 * a.du[i] * dt;                 // [F]:757
-        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;     // [F]:758
+        a.vx[i] = kick_half(a.vx[i], a.ax[i], dt);            // [F]:749-751
+        a.vy[i] = kick_half(a.vy[i], a.ay[i], dt);
+        a.vz[i] = kick_half(a.vz[i], a.az[i], dt);
+        a.u[i] = kick_half(a.u[i], a.du[i], dt);              // [F]:757
+        a.alpha[i] = kick_alpha(a.alpha[i], a.dalpha[i], dt); // [F]:758
     }
     if (blockIdx.x == 0 && threadIdx.x < ns) {                // [F]:753-755
         const int s = threadIdx.x;
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(EW_BLOCK) void drift_kernel(double *__restrict__ x,
     const double dt = dt_ptr ? dt_ptr[0] : dt_val;
     const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     if (i < n) {
-        x[i] = x[i] + vx[i] * dt;                             // [F]:769-771
-        y[i] = y[i] + vy[i] * dt;
-        z[i] = z[i] + vz[i] * dt;
+        x[i] = drift_pos(x[i], vx[i], dt);                    // [F]:769-771
+        y[i] = drift_pos(y[i], vy[i], dt);
+        z[i] = drift_pos(z[i], vz[i], dt);
     }
     if (blockIdx.x == 0 && threadIdx.x < ns) {                // [F]:773-775
         const int s = threadIdx.x;
@@ -66,13 +67,13 @@ __global__ __launch_bounds__(EW_BLOCK) void kick_drift_kernel(KickArgs a, double
     const double dt = dt_ptr[0];
     const int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     if (i < n) {
-        const double vx = a.vx[i] + 0.5 * a.ax[i] * dt, vy = a.vy[i] + 0.5 * a.ay[i] * dt, vz = a.vz[i] + 0.5 * a.az[i] * dt;
+        const double vx = kick_half(a.vx[i], a.ax[i], dt), vy = kick_half(a.vy[i], a.ay[i], dt), vz = kick_half(a.vz[i], a.az[i], dt);
         a.vx[i] = vx; a.vy[i] = vy; a.vz[i] = vz;
-        a.u[i] = a.u[i] + 0.5 * a.du[i] * dt;
-        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;
-        x[i] = x[i] + vx * dt;
-        y[i] = y[i] + vy * dt;
-        z[i] = z[i] + vz * dt;
+        a.u[i] = kick_half(a.u[i], a.du[i], dt);
+        a.alpha[i] = kick_alpha(a.alpha[i], a.dalpha[i], dt);
+        x[i] = drift_pos(x[i], vx, dt);
+        y[i] = drift_pos(y[i], vy, dt);
+        z[i] = drift_pos(z[i], vz, dt);
     }
     if (blockIdx.x == 0 && threadIdx.x < ns) {
         const int s = threadIdx.x;
@@ -101,14 +102,8 @@ __global__ __launch_bounds__(DT_BLOCK) void dt_partial(const double *__restrict_
     double mn = INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
         if (orig[i] >= n_owned) continue;                     // ghosts are timed by their owners
-        const double v2 = vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i];
-        const double a2 = ax[i] * ax[i] + ay[i] * ay[i] + az[i] * az[i];
-        const double c1 = sqrt(v2 / a2);                      // [F]:846
-        const double c2 = u[i] / fabs(du[i]);                 // [F]:847
         const double hi = hvar ? hvar[i] : h;                 // per-particle h: Variable.f90:1053-1054
-        const double c3 = hi / sqrt(v2);                      // [F]:848
-        const double c4 = hi / (cs[i] + 1.2 * cs[i]);         // [F]:849
-        mn = fmin(fmin(fmin(mn, c1), fmin(c2, c3)), c4);      // fmin skips NaN (0/0 candidates)
+        mn = fmin(mn, dt_candidates(vx[i], vy[i], vz[i], ax[i], ay[i], az[i], u[i], du[i], cs[i], hi));      // [F]:846-849
     }
     mn = wave_min(mn);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mn;
@@ -130,19 +125,13 @@ __global__ __launch_bounds__(DT_BLOCK) void kick_dt_kernel(KickArgs a, const dou
     double mn = INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * DT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT_BLOCK) {
         const double ax = a.ax[i], ay = a.ay[i], az = a.az[i], du = a.du[i];
-        const double vx = a.vx[i] + 0.5 * ax * dt, vy = a.vy[i] + 0.5 * ay * dt, vz = a.vz[i] + 0.5 * az * dt;
-        const double u = a.u[i] + 0.5 * du * dt;
+        const double vx = kick_half(a.vx[i], ax, dt), vy = kick_half(a.vy[i], ay, dt), vz = kick_half(a.vz[i], az, dt);
+        const double u = kick_half(a.u[i], du, dt);
         a.vx[i] = vx; a.vy[i] = vy; a.vz[i] = vz; a.u[i] = u;
-        a.alpha[i] = a.alpha[i] + a.dalpha[i] * dt * 0.5;
+        a.alpha[i] = kick_alpha(a.alpha[i], a.dalpha[i], dt);
         if (orig[i] >= n_owned) continue;                     // ghosts are timed by their owners
-        const double v2 = vx * vx + vy * vy + vz * vz;
-        const double a2 = ax * ax + ay * ay + az * az;
-        const double c1 = sqrt(v2 / a2);                      // [F]:846
-        const double c2 = u / fabs(du);                       // [F]:847
         const double hi = hvar ? hvar[i] : h;
-        const double c3 = hi / sqrt(v2);                      // [F]:848
-        const double c4 = hi / (cs[i] + 1.2 * cs[i]);         // [F]:849
-        mn = fmin(fmin(fmin(mn, c1), fmin(c2, c3)), c4);
+        mn = fmin(mn, dt_candidates(vx, vy, vz, ax, ay, az, u, du, cs[i], hi));      // [F]:846-849
     }
     mn = wave_min(mn);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mn;
